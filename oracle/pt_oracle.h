@@ -1,0 +1,74 @@
+/*
+ * pt_oracle.h - TEST INFRASTRUCTURE: CPU restatement of the reference's radiance path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load liboracle.so, and
+ * only as the checker / the timed CPU baseline.  The product (libptgpu.so) never links, loads or
+ * falls back to anything in oracle/.
+ *
+ * Parity status: PINNED.  Every function here is bit-identical (colors, pixels, seeds, NaN
+ * positions) to the reference's own geomfunc.h/simplernd.h/camera.c compiled by gcc from
+ * /root/reference (oracle/_ref, see tests/test_oracle_vs_ref.py), and to the known answers the
+ * survey recorded from the reference's main-cpu.c (tests/test_known_answers.py).
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include "pt_records.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Work counters of the reference algorithm:
+ *   F = 20*sphere_tests + 52*triangle_tests + 70*light_samples + 120*extension_rays */
+typedef struct pt_oracle_counters {
+    uint64_t sphere_tests;
+    uint64_t triangle_tests;
+    uint64_t light_samples;
+    uint64_t extension_rays;
+    uint64_t shadow_rays;
+    uint64_t rng_draws;
+    uint64_t paths;
+} pt_oracle_counters;
+
+enum { ORACLE_SEEDS_CPU_LAYOUT = 0,   /* seeds[2*((H-1-y)*W+x)], reference main-cpu.c:63-66    */
+       ORACLE_SEEDS_KERNEL_LAYOUT = 1 /* seeds[2*(y*W+x)],       reference path-tracing.cl:64-75 */ };
+
+float oracle_get_random(uint32_t *seed0, uint32_t *seed1);                       /* simplernd.h:11-25 */
+void  oracle_camera_ray(const pt_camera *cam, int x, int y, int width, int height,
+                        uint32_t *seed0, uint32_t *seed1, pt_ray *out);           /* main-cpu.c:57-82 */
+int   oracle_intersect(const pt_object *objects, uint32_t n, const pt_ray *ray,
+                       float *t, uint32_t *id);                                  /* geomfunc.h:126-157 */
+int   oracle_intersect_p(const pt_object *objects, uint32_t n, const pt_ray *ray,
+                         float maxt);                                            /* geomfunc.h:162-193 */
+void  oracle_sample_lights(const pt_object *objects, uint32_t n, uint32_t lights,
+                           uint32_t *seed0, uint32_t *seed1, const pt_vec3 *hit,
+                           const pt_vec3 *normal, pt_vec3 *result);              /* geomfunc.h:199-306 */
+void  oracle_radiance(const pt_object *objects, uint32_t n, uint32_t lights, const pt_ray *ray,
+                      uint32_t *seed0, uint32_t *seed1, const pt_scene *scene,
+                      const pt_material *materials, int integrator,
+                      pt_vec3 *radiance);                       /* geomfunc.h:494-798 / 800-1014 */
+uint32_t oracle_accumulate(pt_vec3 *color, const pt_vec3 *sample, int current_sample,
+                           float gamma);                                         /* main-cpu.c:89-103 */
+
+/* One progressive pass, main-cpu.c:54-110.  colors[(H-1-y)*W+x], pixels[y*W+x].
+ * threads <= 1 is the reference's serial loop; > 1 splits rows over OpenMP threads (pixels are
+ * independent, results are identical). */
+void oracle_render_pass(const pt_object *objects, uint32_t n, uint32_t lights,
+                        const pt_material *materials, const pt_camera *cam, const pt_scene *scene,
+                        int width, int height, uint32_t *seeds, pt_vec3 *colors, uint32_t *pixels,
+                        int current_sample, int integrator, int seed_layout, int threads);
+
+/* Same, serial, also counting the work done (counters are added to, not reset). */
+void oracle_render_pass_counted(const pt_object *objects, uint32_t n, uint32_t lights,
+                                const pt_material *materials, const pt_camera *cam,
+                                const pt_scene *scene, int width, int height, uint32_t *seeds,
+                                pt_vec3 *colors, uint32_t *pixels, int current_sample,
+                                int integrator, int seed_layout, pt_oracle_counters *counters);
+
+int oracle_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,187 @@
+"""ctypes bindings over the two C-ABI libraries of this repo (plumbing for tests and bench.py).
+
+  libpthost.so  plain-C host side: scene reader, OBJ ingestion, camera basis, seeds, PPM
+                (include/pthost.h)
+  libptgpu.so   the HIP radiance path (include/ptgpu.h)
+
+Nothing here computes anything: every call goes straight through the C-ABI.  There is no CPU
+fallback; `gpu()` raises if libptgpu.so is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+DATA_DIR = os.path.join(REPO, "data")
+
+
+class Vec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+    def tuple(self):
+        return (self.x, self.y, self.z)
+
+
+class Ray(C.Structure):
+    _fields_ = [("o", Vec3), ("d", Vec3)]
+
+
+class Object(C.Structure):
+    _fields_ = [("type", C.c_int16), ("material_id", C.c_int16), ("emission", Vec3), ("color", Vec3),
+                ("radius", C.c_float), ("center", Vec3), ("p1", Vec3), ("p2", Vec3), ("p3", Vec3),
+                ("area", C.c_float)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int16), ("pad_", C.c_int16), ("kd", Vec3), ("ks", Vec3),
+                ("sigma", C.c_float), ("roughness", C.c_float), ("A", C.c_float), ("B", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("orig", Vec3), ("target", Vec3), ("pitch", C.c_float), ("yaw", C.c_float),
+                ("width", C.c_float), ("height", C.c_float), ("dir", Vec3), ("x", Vec3), ("y", Vec3)]
+
+
+class Scene(C.Structure):
+    _fields_ = [("gamma", C.c_float), ("sky1", Vec3), ("sky2", Vec3), ("material_count", C.c_uint32)]
+
+
+class HostScene(C.Structure):
+    _fields_ = [("scene", Scene), ("camera", Camera), ("objects", C.POINTER(Object)),
+                ("object_count", C.c_uint32), ("light_count", C.c_uint32),
+                ("materials", C.POINTER(Material)), ("title", C.c_char * 100)]
+
+
+assert C.sizeof(Vec3) == 12 and C.sizeof(Ray) == 24 and C.sizeof(Object) == 84
+assert C.sizeof(Material) == 44 and C.sizeof(Camera) == 76 and C.sizeof(Scene) == 32
+
+OBJECT_DTYPE = np.dtype([("type", "<i2"), ("material_id", "<i2"), ("emission", "<f4", 3),
+                         ("color", "<f4", 3), ("radius", "<f4"), ("center", "<f4", 3),
+                         ("p1", "<f4", 3), ("p2", "<f4", 3), ("p3", "<f4", 3), ("area", "<f4")])
+MATERIAL_DTYPE = np.dtype([("type", "<i2"), ("pad_", "<i2"), ("kd", "<f4", 3), ("ks", "<f4", 3),
+                           ("sigma", "<f4"), ("roughness", "<f4"), ("A", "<f4"), ("B", "<f4")])
+assert OBJECT_DTYPE.itemsize == 84 and MATERIAL_DTYPE.itemsize == 44
+
+_host = None
+_gpu = None
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def host():
+    """libpthost.so, loaded once."""
+    global _host
+    if _host is None:
+        lib = C.CDLL(os.path.join(HERE, "libpthost.so"))
+        lib.pthost_last_error.restype = C.c_char_p
+        lib.pthost_load_scene.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(HostScene)]
+        lib.pthost_free_scene.argtypes = [C.POINTER(HostScene)]
+        lib.pthost_update_camera_basis.argtypes = [C.POINTER(Camera)]
+        lib.pthost_seed_block.argtypes = [C.c_void_p, C.c_size_t, C.c_uint64]
+        lib.pthost_seed_block.restype = None
+        lib.pthost_flip_rows_u32x2.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        lib.pthost_flip_rows_u32x2.restype = None
+        lib.pthost_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        lib.pthost_obj_load.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_uint32),
+                                        C.POINTER(C.c_uint32)]
+        lib.pthost_obj_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(C.c_float)),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_int32)),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.pthost_snapshot_name.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_int, C.c_double]
+        lib.pthost_snapshot_name.restype = None
+        lib.pthost_captions.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_double, C.c_double,
+                                        C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.pthost_captions.restype = None
+        lib.pthost_frame_time_budget.argtypes = [C.c_int]
+        lib.pthost_frame_time_budget.restype = C.c_float
+        _host = lib
+    return _host
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class LoadedScene:
+    """A scene read by libpthost, with numpy views over the malloc()ed record arrays."""
+
+    def __init__(self, name_or_path, width, height, model_dir=DATA_DIR):
+        path = name_or_path
+        if not os.path.exists(path):
+            path = os.path.join(DATA_DIR, "scenes", name_or_path + ".txt")
+        self.raw = HostScene()
+        rc = host().pthost_load_scene(path.encode(), model_dir.encode() if model_dir else None,
+                                      width, height, C.byref(self.raw))
+        if rc != 0:
+            raise HostError(host().pthost_last_error().decode())
+        host().pthost_update_camera_basis(C.byref(self.raw.camera))
+        self.width, self.height = width, height
+        n = self.raw.object_count
+        m = self.raw.scene.material_count
+        self.objects = np.ctypeslib.as_array(
+            C.cast(self.raw.objects, C.POINTER(C.c_uint8)), shape=(n * 84,)).view(OBJECT_DTYPE).copy()
+        self.materials = np.ctypeslib.as_array(
+            C.cast(self.raw.materials, C.POINTER(C.c_uint8)), shape=(m * 44,)).view(MATERIAL_DTYPE).copy()
+        self.camera = Camera.from_buffer_copy(self.raw.camera)
+        self.scene = Scene.from_buffer_copy(self.raw.scene)
+        self.object_count = int(n)
+        self.light_count = int(self.raw.light_count)
+        self.title = self.raw.title.decode()
+        host().pthost_free_scene(C.byref(self.raw))
+
+    def set_view(self, yaw=0.0, pitch=0.0, orig=None):
+        self.camera.yaw, self.camera.pitch = yaw, pitch
+        if orig is not None:
+            self.camera.orig = Vec3(*orig)
+        host().pthost_update_camera_basis(C.byref(self.camera))
+
+
+def seed_block(width, height, rank=0):
+    """2*W*H rand()-compatible seeds; rank g takes the g-th consecutive block."""
+    n = 2 * width * height
+    seeds = np.empty(n, dtype=np.uint32)
+    host().pthost_seed_block(_ptr(seeds), n, rank * n)
+    return seeds
+
+
+def flip_rows(seeds, width, height):
+    out = np.ascontiguousarray(seeds).copy()
+    host().pthost_flip_rows_u32x2(_ptr(out), width, height)
+    return out
+
+
+def obj_load(path):
+    v = C.POINTER(C.c_float)()
+    idx = C.POINTER(C.c_int32)()
+    nv, nc, nf = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = host().pthost_obj_load(path.encode(), C.byref(v), C.byref(nv), C.byref(idx), C.byref(nc), C.byref(nf))
+    if rc != 0:
+        raise HostError(host().pthost_last_error().decode())
+    verts = np.ctypeslib.as_array(v, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy()
+    corners = np.ctypeslib.as_array(idx, shape=(max(nc.value, 1),))[: nc.value].copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(v)
+    libc.free(idx)
+    return verts.reshape(-1, 3), corners, nf.value
+
+
+def obj_parse(data: bytes):
+    v = C.POINTER(C.c_float)()
+    idx = C.POINTER(C.c_int32)()
+    nv, nc, nf = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = host().pthost_obj_parse(data, len(data), C.byref(v), C.byref(nv), C.byref(idx), C.byref(nc), C.byref(nf))
+    if rc != 0:
+        raise HostError(host().pthost_last_error().decode())
+    verts = np.ctypeslib.as_array(v, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy()
+    corners = np.ctypeslib.as_array(idx, shape=(max(nc.value, 1),))[: nc.value].copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(v)
+    libc.free(idx)
+    return verts.reshape(-1, 3), corners, nf.value

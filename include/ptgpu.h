@@ -1,0 +1,141 @@
+/*
+ * ptgpu.h - C-ABI of the MI355X radiance path (libptgpu.so, HIP for gfx950).
+ *
+ * Drop-in boundary: these entry points stand where the OpenCL host plumbing of the reference's
+ * main-gpu.c stands, between the UI's three entry points (displayfunc.c:19-21) and the
+ * `radianceGPU` kernel (path-tracing.cl:49-61 / ray-tracing.cl:32-45).  Records cross the boundary
+ * in the reference's own byte layout (include/pt_records.h); all host arrays stay caller-owned and
+ * are copied by the call (the reference uses blocking writes), device buffers are library-owned.
+ *
+ * Errors: the reference prints to stderr and exit(-1)s on any OpenCL failure (e.g.
+ * main-gpu.c:709-712).  Here every call returns PTGPU_OK (0) or a negative status and
+ * ptgpu_last_error() holds the message; nothing is printed and nothing exits.
+ *
+ * Threading: like the reference (one in-order queue, GLUT idle callback) a context is driven by
+ * one host thread at a time; work is issued on one HIP stream owned by the context.
+ *
+ * There is no CPU path behind this interface: without a HIP device every call fails.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include "pt_records.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ptgpu_ctx ptgpu_ctx;
+
+enum {
+    PTGPU_OK            = 0,
+    PTGPU_ERR_ARGUMENT  = -1, /* null pointer, size out of range, material index out of range ... */
+    PTGPU_ERR_STATE     = -2, /* call order: render before set_scene/resize ...                    */
+    PTGPU_ERR_DEVICE    = -3, /* a HIP call failed; message carries hipGetErrorString()            */
+    PTGPU_ERR_MEMORY    = -4
+};
+
+/* options for ptgpu_set_option */
+enum {
+    PTGPU_OPT_KERNEL = 0, /* PTGPU_KERNEL_*  (default WAVEFRONT)                        */
+    PTGPU_OPT_MATH   = 1, /* PTGPU_MATH_*    (default FAST)                             */
+    PTGPU_OPT_LDS    = 2  /* 1 = stage primitive/light records in LDS (default), 0 = read them
+                             with wave-uniform (scalar) loads from global memory        */
+};
+enum {
+    PTGPU_KERNEL_MEGA      = 0, /* one thread = one pixel = one whole path; the direct counterpart of
+                                   the reference kernel's shape, kept as the measured baseline  */
+    PTGPU_KERNEL_WAVEFRONT = 1  /* wave-autonomous wavefront tracer: shadow rays compacted into
+                                   per-wave LDS queues and traced by dense 64-lane batches       */
+};
+enum {
+    PTGPU_MATH_FAST   = 0, /* FMA contraction on, v_rcp/v_rsq/v_sqrt/v_sin/v_cos f32 approximations:
+                              statistical parity (tests state the tolerance)                        */
+    PTGPU_MATH_STRICT = 1  /* no contraction, IEEE f32 divide/sqrt, and f64 exactly where the
+                              reference's host build promotes to double: bit-level parity vehicle  */
+};
+
+/* replaces setUpOpenCL()'s platform/device/context/queue/program/kernel set-up,
+ * reference main-gpu.c:216-506, 595-677.  Kernels are compiled ahead of time for gfx950.
+ * integrator: PT_INTEGRATOR_PT (path-tracing.cl) or PT_INTEGRATOR_DL (ray-tracing.cl), the
+ * reference's argv[3] (main-gpu.c:927). */
+int ptgpu_create(ptgpu_ctx **out, int device_ordinal, int integrator);
+
+/* replaces the release calls, reference main-gpu.c:58-80 */
+int ptgpu_destroy(ptgpu_ctx *ctx);
+
+int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value);
+
+/* replaces the object/material buffer creation + blocking writes, reference main-gpu.c:516-559,
+ * and reInitSceneObjects(), :862-880.  `light_count` is the reference's lightCount kernel
+ * argument (main-gpu.c:764): light sampling visits emissive objects in index order until that
+ * many have been seen (geomfunc.h:220).  `scene` carries gamma and the two sky colours, passed
+ * by value to the reference kernel (main-gpu.c:767).  Fails with PTGPU_ERR_ARGUMENT if an
+ * object's material_id is >= material_count (the reference would read past the buffer). */
+int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_count,
+                    uint32_t light_count, const pt_material *materials, uint32_t material_count,
+                    const pt_scene *scene);
+
+/* replaces the camera buffer write, reference main-gpu.c:563-586 and
+ * reInitViewpointDependentBuffers(), :885-913.  The basis (dir, x, y) must already be computed
+ * (pthost_update_camera_basis).  The caller resets its sample counter, as the reference does. */
+int ptgpu_set_camera(ptgpu_ctx *ctx, const pt_camera *camera);
+
+/* replaces allocateOutputBuffers()/freeBuffers(), reference main-gpu.c:85-168, 58-80:
+ * (re)allocates colour (12*W*H), pixel (4*W*H) and seed (8*W*H) buffers and uploads the seeds.
+ * seeds: 2*W*H words, pixel (x, y) uses seeds[2*(y*W+x)] and [..+1] (path-tracing.cl:64-75). */
+int ptgpu_resize(ptgpu_ctx *ctx, int width, int height, const uint32_t *seeds);
+
+/* replaces the 13 clSetKernelArg + executeKernel(), reference main-gpu.c:734-776, 682-713:
+ * enqueues ONE pass (one path per pixel).  current_sample is the host's counter
+ * (current_sample == 0 overwrites the running mean, path-tracing.cl:88-90).  Asynchronous. */
+int ptgpu_render_pass(ptgpu_ctx *ctx, int current_sample);
+
+/* n_passes consecutive passes starting at first_sample (the inner loop of updateRendering(),
+ * reference main-gpu.c:782-793, without its per-pass clFinish).  Asynchronous. */
+int ptgpu_render(ptgpu_ctx *ctx, int first_sample, int n_passes);
+
+/* Same as ptgpu_render but bracketed by HIP events on the context's stream; blocks until done and
+ * returns the elapsed device time in milliseconds.  (Measurement aid, no reference counterpart.) */
+int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *elapsed_ms);
+
+/* replaces clFinish(), reference main-gpu.c:786 */
+int ptgpu_finish(ptgpu_ctx *ctx);
+
+/* replaces the blocking read of pixelBuffer, reference main-gpu.c:803-816.
+ * pixels[y*W+x] = R | G<<8 | B<<16 after gamma (path-tracing.cl:113-116); a NaN radiance packs
+ * to 0x80000000 as on the reference's CPU path. */
+int ptgpu_read_pixels(ptgpu_ctx *ctx, uint32_t *pixels);
+
+/* Additions (the reference never reads colorBuffer or seedBuffer back, main-gpu.c:88, 803-827):
+ * linear running-mean radiance, 3 floats per pixel at [(H-1-y)*W+x] (path-tracing.cl:87), and
+ * the current RNG state.  Needed for parity checks, multi-GPU reduction and checkpointing. */
+int ptgpu_read_colors(ptgpu_ctx *ctx, float *colors_xyz);
+int ptgpu_read_seeds(ptgpu_ctx *ctx, uint32_t *seeds);
+int ptgpu_write_colors(ptgpu_ctx *ctx, const float *colors_xyz);
+
+/* Multi-GPU support (no reference counterpart): the device address of the colour
+ * buffer (3*W*H floats) so a caller can all-reduce it in place with RCCL, the stream the library
+ * works on, and a re-pack of `pixels` from the (reduced) colour buffer scaled by `scale`
+ * (1/ranks after a sum all-reduce of equal-pass running means). */
+int ptgpu_colors_device_ptr(ptgpu_ctx *ctx, void **device_ptr);
+int ptgpu_stream(ptgpu_ctx *ctx, void **hip_stream);
+int ptgpu_scale_and_repack(ptgpu_ctx *ctx, float scale);
+
+/* Counters of the last set_scene (what was staged on the device). */
+typedef struct ptgpu_scene_info {
+    uint32_t primitives;   /* spheres + triangles (MODEL placeholders dropped) */
+    uint32_t spheres;
+    uint32_t triangles;
+    uint32_t lights;       /* min(light_count, emissive primitives) */
+    uint32_t segments;     /* runs of equal primitive type in index order */
+    uint32_t lds_bytes;    /* LDS the staged records take per workgroup (0 = not staged) */
+} ptgpu_scene_info;
+int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
+
+const char *ptgpu_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

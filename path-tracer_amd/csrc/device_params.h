@@ -1,0 +1,55 @@
+// device_params.h - what the host side of libptgpu hands to the kernels, and the packed
+// device-side scene layout.  Shared by ptgpu_api.hip and the two kernel translation units.
+//
+// Device scene layout (built once per ptgpu_set_scene, all arrays of float4 in HBM, read-only):
+//
+//   prims  [3 * n_prims]   primitive p = the p-th non-MODEL object in index order
+//        sphere  : a = (center.xyz, radius)  b = (radius*radius, 0, 0, 0)   c = 0
+//        triangle: a = (p1.xyz, 0)           b = (e1.xyz, 0) = p2 - p1      c = (e2.xyz, 0) = p3 - p1
+//     (e1, e2 and radius^2 are the same single float operations the reference performs on every
+//      test, geomfunc.h:17, 48-49, so hoisting them is bit-neutral.)
+//   segs   [n_segs]        runs of equal primitive type in index order: (type, begin, end, 0).
+//     Index order is kept so closest-hit ties resolve to the lowest index as in the reference
+//     (geomfunc.h:149); the run structure makes the inner loops type-pure.
+//   shade  [4 * n_prims]   s0 = (emission.xyz, flags)  flags = material type | emissive << 8 | prim type << 16
+//                          s1 = (color.xyz, sigma)  s2 = (kd.xyz, A)  s3 = (B, 0, 0, 0)
+//   lights [4 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
+//                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0)  l2 = (e2)  l3 = (emission.xyz, area)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct PtDeviceParams {
+    const float4 *prims;
+    const float4 *shade;
+    const float4 *lights;
+    const int4   *segs;
+    int n_prims, n_segs, n_lights, integrator;
+    float cam_orig[3], cam_dir[3], cam_x[3], cam_y[3];
+    float sky1[3], sky2[3];
+    float gamma;
+    int width, height;
+    int current_sample;   // sample index of the first pass of this launch
+    int n_passes;         // passes done inside this launch (wavefront kernel keeps state in registers)
+    float    *colors;     // 3 floats per pixel at (H-1-y)*W+x
+    uint32_t *pixels;     // y*W+x
+    uint32_t *seeds;      // 2 words per pixel at y*W+x
+    int tiles_x;          // image width in 8x8 pixel tiles (one wave = one tile)
+    int n_tiles;
+};
+
+struct PtLaunchConfig {
+    int use_lds;          // stage prims+lights in LDS
+    unsigned lds_bytes;   // dynamic LDS for the staged records
+};
+
+namespace ptk_fast {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
+}
+namespace ptk_strict {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
+}

@@ -185,3 +185,160 @@ def obj_parse(data: bytes):
     libc.free(v)
     libc.free(idx)
     return verts.reshape(-1, 3), corners, nf.value
+
+
+# ---------------------------------------------------------------------------------------------
+# libptgpu.so (HIP).  No fallback: a missing library or a missing GPU raises.
+# ---------------------------------------------------------------------------------------------
+OPT_KERNEL, OPT_MATH, OPT_LDS = 0, 1, 2
+KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
+MATH_FAST, MATH_STRICT = 0, 1
+INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("primitives", "spheres", "triangles", "lights", "segments", "lds_bytes")]
+
+
+GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_scene", "ptgpu_set_camera",
+               "ptgpu_resize", "ptgpu_render_pass", "ptgpu_render", "ptgpu_render_timed", "ptgpu_finish",
+               "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
+               "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
+               "ptgpu_last_error"]
+
+
+class GpuError(RuntimeError):
+    pass
+
+
+def gpu():
+    """libptgpu.so, loaded once.  Raises if the HIP extension has not been built."""
+    global _gpu
+    if _gpu is None:
+        path = os.path.join(HERE, "libptgpu.so")
+        if not os.path.exists(path):
+            raise GpuError("libptgpu.so is missing: build it with `make -C path-tracer_amd/csrc` "
+                           "(there is no CPU fallback for the radiance path)")
+        lib = C.CDLL(path)
+        lib.ptgpu_last_error.restype = C.c_char_p
+        vp = C.c_void_p
+        lib.ptgpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        lib.ptgpu_destroy.argtypes = [vp]
+        lib.ptgpu_set_option.argtypes = [vp, C.c_int, C.c_int]
+        lib.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(Scene)]
+        lib.ptgpu_set_camera.argtypes = [vp, C.POINTER(Camera)]
+        lib.ptgpu_resize.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.ptgpu_render_pass.argtypes = [vp, C.c_int]
+        lib.ptgpu_render.argtypes = [vp, C.c_int, C.c_int]
+        lib.ptgpu_render_timed.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+        lib.ptgpu_finish.argtypes = [vp]
+        lib.ptgpu_read_pixels.argtypes = [vp, vp]
+        lib.ptgpu_read_colors.argtypes = [vp, vp]
+        lib.ptgpu_read_seeds.argtypes = [vp, vp]
+        lib.ptgpu_write_colors.argtypes = [vp, vp]
+        lib.ptgpu_colors_device_ptr.argtypes = [vp, C.POINTER(vp)]
+        lib.ptgpu_stream.argtypes = [vp, C.POINTER(vp)]
+        lib.ptgpu_scale_and_repack.argtypes = [vp, C.c_float]
+        lib.ptgpu_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        _gpu = lib
+    return _gpu
+
+
+class Gpu:
+    """One ptgpu context driven the way main-gpu.c drives its OpenCL objects."""
+
+    def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None):
+        self.lib = gpu()
+        self.ctx = C.c_void_p()
+        self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
+        if kernel is not None:
+            self.set_option(OPT_KERNEL, kernel)
+        if math is not None:
+            self.set_option(OPT_MATH, math)
+        if lds is not None:
+            self.set_option(OPT_LDS, lds)
+        self.w = self.h = 0
+        self.sample = 0
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise GpuError("ptgpu status %d: %s" % (rc, self.lib.ptgpu_last_error().decode()))
+
+    def set_option(self, opt, value):
+        self._ok(self.lib.ptgpu_set_option(self.ctx, opt, value))
+
+    def set_scene(self, sc, light_count=None):
+        self._ok(self.lib.ptgpu_set_scene(self.ctx, _ptr(sc.objects), sc.object_count,
+                                          sc.light_count if light_count is None else light_count,
+                                          _ptr(sc.materials), len(sc.materials), C.byref(sc.scene)))
+        self._ok(self.lib.ptgpu_set_camera(self.ctx, C.byref(sc.camera)))
+
+    def set_camera(self, camera):
+        self._ok(self.lib.ptgpu_set_camera(self.ctx, C.byref(camera)))
+
+    def resize(self, w, h, seeds):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        assert seeds.size == 2 * w * h
+        self._ok(self.lib.ptgpu_resize(self.ctx, w, h, _ptr(seeds)))
+        self.w, self.h, self.sample = w, h, 0
+
+    def render(self, n_passes=1):
+        self._ok(self.lib.ptgpu_render(self.ctx, self.sample, n_passes))
+        self.sample += n_passes
+
+    def render_pass(self):
+        self._ok(self.lib.ptgpu_render_pass(self.ctx, self.sample))
+        self.sample += 1
+
+    def render_timed(self, n_passes):
+        ms = C.c_float()
+        self._ok(self.lib.ptgpu_render_timed(self.ctx, self.sample, n_passes, C.byref(ms)))
+        self.sample += n_passes
+        return ms.value
+
+    def finish(self):
+        self._ok(self.lib.ptgpu_finish(self.ctx))
+
+    def pixels(self):
+        out = np.empty(self.w * self.h, dtype=np.uint32)
+        self._ok(self.lib.ptgpu_read_pixels(self.ctx, _ptr(out)))
+        return out
+
+    def colors(self):
+        out = np.empty((self.w * self.h, 3), dtype=np.float32)
+        self._ok(self.lib.ptgpu_read_colors(self.ctx, _ptr(out)))
+        return out
+
+    def seeds(self):
+        out = np.empty(2 * self.w * self.h, dtype=np.uint32)
+        self._ok(self.lib.ptgpu_read_seeds(self.ctx, _ptr(out)))
+        return out
+
+    def write_colors(self, colors):
+        colors = np.ascontiguousarray(colors, dtype=np.float32)
+        assert colors.size == 3 * self.w * self.h
+        self._ok(self.lib.ptgpu_write_colors(self.ctx, _ptr(colors)))
+
+    def colors_device_ptr(self):
+        p = C.c_void_p()
+        self._ok(self.lib.ptgpu_colors_device_ptr(self.ctx, C.byref(p)))
+        return p.value
+
+    def scale_and_repack(self, scale):
+        self._ok(self.lib.ptgpu_scale_and_repack(self.ctx, scale))
+
+    def scene_info(self):
+        info = SceneInfo()
+        self._ok(self.lib.ptgpu_get_scene_info(self.ctx, C.byref(info)))
+        return {n: int(getattr(info, n)) for n, _ in info._fields_}
+
+    def close(self):
+        if self.ctx:
+            self.lib.ptgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py - Mpaths/s of the radiance path on scenes/cornell.txt 1024x768 (BASELINE.json config 2).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = `--passes` progressive passes (one path per pixel per pass) over the whole frame, issued
+through the C-ABI as ONE kernel launch.  Inputs (scene records, seeds, colour buffer) are resident
+in HBM before the timed region; the region is K steps bracketed by a barrier + device sync, MAX over
+ranks.  With N > 1 each rank renders from its own seed block and the colour buffers are summed with
+one RCCL all-reduce inside the timed region (weak scaling: per-GPU work is fixed).
+
+The JSON line also carries
+  roofline     FP32 VALU: reference-equivalent flops F per path (counted by the CPU
+               oracle on a sample of the same scene) x paths per launch / average launch duration
+               from HIP events on the library's stream, against 157.3 TFLOP/s.
+  cpu_baseline the CPU oracle (a bit-exact port of the reference's main-cpu.c path) timed on this
+               host's cores on a bounded sample of the same scene.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
+
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 x 2.4 GHz
+
+
+def cpu_baseline(scene_name):
+    """Rank 0, N = 1 only.  oracle/ is used here as the timed CPU baseline and the flop counter."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_binding as ob
+    import pyptgpu as pt
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    # flops per path of the reference algorithm, counted on a 96x72 frame (serial, counting build)
+    cw, ch = 96, 72
+    sc = pt.LoadedScene(scene_name, cw, ch)
+    ctr = ob.Counters()
+    t0 = time.perf_counter()
+    ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle_counted(ctr, 1)
+    t_count = time.perf_counter() - t0
+    flops_per_path = ctr.flops() / ctr.paths
+    # single thread = the reference's serial loop (main-cpu.c:61-62)
+    t0 = time.perf_counter()
+    ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle(1, threads=1)
+    t_one = time.perf_counter() - t0
+    one = cw * ch / t_one / 1e6
+    # all threads, sized for ~10-20 s of wall time
+    paths_target = max(one * 1e6 * threads * 12.0, cw * ch)
+    scale = max(1, int((paths_target / (cw * ch)) ** 0.5))
+    bw, bh = min(1024, cw * scale) // 8 * 8, min(768, ch * scale) // 8 * 8
+    scb = pt.LoadedScene(scene_name, bw, bh)
+    t0 = time.perf_counter()
+    ob.Render(scb, pt.seed_block(bw, bh)).pass_oracle(1, threads=threads)
+    t_all = time.perf_counter() - t0
+    return {
+        "value": bw * bh / t_all / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+        "sample": f"{scene_name} {bw}x{bh} x 1 spp, {threads} OpenMP threads over rows, {t_all:.1f} s",
+        "single_thread_value": one,
+        "single_thread_sample": f"{scene_name} {cw}x{ch} x 1 spp, serial loop as main-cpu.c, {t_one:.1f} s",
+    }, flops_per_path, ctr.as_dict()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--passes", type=int, default=8, help="progressive passes per step (= per launch)")
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=768)
+    ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
+    ap.add_argument("--math", default="fast", choices=["fast", "strict"])
+    ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import multigpu
+    import pyptgpu as pt
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the radiance path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h = args.width, args.height
+    sc = pt.LoadedScene(args.scene, w, h)
+    seeds = pt.seed_block(w, h, rank)
+    g = pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
+               kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
+               math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT)
+    g.set_scene(sc)
+    g.resize(w, h, seeds)
+    colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * w * h),
+                               device=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        g.finish()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        g.render_timed(args.passes)
+    barrier()
+    launch_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        launch_ms.append(g.render_timed(args.passes))  # HIP events on the library's stream
+    g.finish()
+    scale = multigpu.allreduce_mean_(colors_t, world)  # the one collective of the path
+    torch.cuda.synchronize()
+    g.scale_and_repack(scale)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    paths_per_launch = w * h * args.passes
+    total_paths = paths_per_launch * args.steps * world
+    value = total_paths / elapsed / 1e6
+
+    if rank == 0:
+        pixels = g.pixels()
+        baseline, flops_per_path, counters = (None, None, None)
+        if world == 1 and not args.no_cpu:
+            baseline, flops_per_path, counters = cpu_baseline(args.scene)
+        avg_launch_ms = sum(launch_ms) / len(launch_ms)
+        roofline = None
+        if flops_per_path is not None:
+            achieved = flops_per_path * paths_per_launch / (avg_launch_ms * 1e-3) / 1e12
+            roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                        "kernel": f"radiance_{args.kernel}_kernel ({args.math})",
+                        "avg_launch_ms": avg_launch_ms,
+                        "algorithmic_flops_per_path": flops_per_path,
+                        "paths_per_launch": paths_per_launch,
+                        "hbm_algorithmic_bytes_per_launch": 44 * w * h}
+        line = {
+            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "scene file data/scenes/%s.txt (the reference's own), rand()-compatible seeds" % args.scene,
+            "config": {"workload": f"{args.scene}.txt {w}x{h}, {args.passes} passes/step, "
+                                   f"{args.integrator} integrator, {args.kernel} kernel, {args.math} math",
+                       "spp_timed": args.steps * args.passes, "spp_per_s": args.steps * args.passes * world / elapsed,
+                       "parallelism": f"passes split over {world} GPU(s) by seed block + 1 all-reduce"},
+            "roofline": roofline, "cpu_baseline": baseline,
+            "speedup_vs_cpu_all_cores": (value / world / baseline["value"]) if baseline else None,
+            "speedup_vs_cpu_single_thread": (value / world / baseline["single_thread_value"]) if baseline else None,
+            "oracle_counters_sample": counters,
+            "nan_pixels": int((pixels == 0x80000000).sum()),
+        }
+        print(json.dumps(line), flush=True)
+    g.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

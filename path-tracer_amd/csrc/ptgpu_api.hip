@@ -35,7 +35,7 @@ int fail(int code, const char *fmt, ...) {
 
 // LDS we are willing to spend on staged records per workgroup; beyond it the kernels read the
 // records with wave-uniform loads from global memory instead (160 KiB per CU on gfx950).
-constexpr unsigned kMaxStagedLdsBytes = 96 * 1024;
+constexpr unsigned kMaxStagedLdsBytes = 96 * 1024; // + 58 KiB of per-wave scratch in the wavefront kernel
 
 bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 0.f)); } // vec.h:23
 
@@ -44,7 +44,7 @@ bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 
 struct ptgpu_ctx {
     int device = 0;
     int integrator = PT_INTEGRATOR_PT;
-    int kernel = PTGPU_KERNEL_MEGA;
+    int kernel = PTGPU_KERNEL_WAVEFRONT;
     int math = PTGPU_MATH_FAST;
     int want_lds = 1;
     hipStream_t stream = nullptr;

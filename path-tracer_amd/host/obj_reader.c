@@ -13,8 +13,9 @@
  *    keeps all its lines (cylinder 123/124 faces, teapot 239/240, ...);
  *  - numbers are read by the loader's own decimal routine (:267-393), not strtod: the fraction is
  *    summed digit by digit with repeated multiplication by 0.1, and a decimal exponent e is applied
- *    as 5^e * (1 << e), which for negative e is x86's masked shift (bunny.obj's "e-003" becomes
- *    * 2^29, so the reference cannot load that file sensibly either);
+ *    as 5^e * (1 << e); for negative e the reference's build multiplies by 1, i.e. it IGNORES
+ *    negative exponents (bunny.obj's "-3.41e-003" loads as -3.41: the reference cannot load that
+ *    file sensibly, and neither do we - same bytes);
  *  - `f` corners: "i", "i/j", "i//k", "i/j/k"; positive indices are 1-based, 0 stays 0, negative
  *    ones are relative to the vertices seen so far (:176-180).
  */
@@ -88,9 +89,10 @@ static int obj_parse_decimal(const char *s, const char *end, double *out) {
 assemble: {
     double five = 1.0;
     for (int k = 0; k < expo; ++k) five = five * 5.0;
-    /* (1 << expo) with a negative count is undefined in C; the reference runs on x86-64 where
-     * the count is taken modulo 32, which is what we pin here. */
-    int two = (int)(1u << ((unsigned)expo & 31u));
+    /* (1 << expo) is undefined in C for expo < 0 or expo > 31.  Pinned to what the reference's
+     * gcc 11.4 -O3 x86-64 build does (probed through oracle/_ref, tests/test_host_reader.py):
+     * a negative exponent multiplies by 1, a large one takes the count modulo 32. */
+    int two = expo < 0 ? 1 : (int)(1u << ((unsigned)expo & 31u));
     *out = (sgn == '+' ? 1 : -1) * (mant * five) * (double)two;
 }
     return 1;

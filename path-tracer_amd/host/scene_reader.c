@@ -263,6 +263,7 @@ int pthost_load_scene(const char *path, const char *model_dir, int width, int he
     for (unsigned li = 0; li < declared; ++li) {
         uint32_t slot = li + added;
         pt_object *obj = &out->objects[slot];
+        memset(obj, 0, sizeof *obj); /* the table may have been realloc()ed: no stale bytes */
         char kind[100];
         unsigned mat = 0;
         int got = fscanf(f, "%99s", kind);

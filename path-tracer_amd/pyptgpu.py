@@ -155,6 +155,18 @@ def flip_rows(seeds, width, height):
     return out
 
 
+def _take_obj(v, nv, idx, nc, nf):
+    verts = (np.ctypeslib.as_array(v, shape=(nv.value * 3,)).copy() if nv.value and v
+             else np.zeros(0, np.float32))
+    corners = (np.ctypeslib.as_array(idx, shape=(nc.value,)).copy() if nc.value and idx
+               else np.zeros(0, np.int32))
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(v)
+    libc.free(idx)
+    return verts.reshape(-1, 3), corners, nf.value
+
+
 def obj_load(path):
     v = C.POINTER(C.c_float)()
     idx = C.POINTER(C.c_int32)()
@@ -162,13 +174,7 @@ def obj_load(path):
     rc = host().pthost_obj_load(path.encode(), C.byref(v), C.byref(nv), C.byref(idx), C.byref(nc), C.byref(nf))
     if rc != 0:
         raise HostError(host().pthost_last_error().decode())
-    verts = np.ctypeslib.as_array(v, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy()
-    corners = np.ctypeslib.as_array(idx, shape=(max(nc.value, 1),))[: nc.value].copy()
-    libc = C.CDLL(None)
-    libc.free.argtypes = [C.c_void_p]
-    libc.free(v)
-    libc.free(idx)
-    return verts.reshape(-1, 3), corners, nf.value
+    return _take_obj(v, nv, idx, nc, nf)
 
 
 def obj_parse(data: bytes):
@@ -178,13 +184,7 @@ def obj_parse(data: bytes):
     rc = host().pthost_obj_parse(data, len(data), C.byref(v), C.byref(nv), C.byref(idx), C.byref(nc), C.byref(nf))
     if rc != 0:
         raise HostError(host().pthost_last_error().decode())
-    verts = np.ctypeslib.as_array(v, shape=(max(nv.value, 1) * 3,))[: nv.value * 3].copy()
-    corners = np.ctypeslib.as_array(idx, shape=(max(nc.value, 1),))[: nc.value].copy()
-    libc = C.CDLL(None)
-    libc.free.argtypes = [C.c_void_p]
-    libc.free(v)
-    libc.free(idx)
-    return verts.reshape(-1, 3), corners, nf.value
+    return _take_obj(v, nv, idx, nc, nf)
 
 
 # ---------------------------------------------------------------------------------------------

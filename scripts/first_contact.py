@@ -19,20 +19,24 @@ def run(name, w, h, spp, integ, math, kernel=pt.KERNEL_MEGA, lds=1):
           f"pixels-equal {(pix==cpu.pixels).mean()*100:.2f}% maxabs {d.max():.3g} rmse {np.sqrt((d**2).mean()):.3g} nan gpu/cpu {int(np.isnan(col).any(1).sum())}/{int(np.isnan(cpu.colors).any(1).sum())} {dt*1e3:.1f} ms", flush=True)
     g.close()
 
+K = pt.KERNEL_WAVEFRONT
 for math in (pt.MATH_STRICT, pt.MATH_FAST):
     for lds in (1, 0):
-        run("cornell-large", 64, 48, 4, 0, math, lds=lds)
-    run("simple", 64, 48, 4, 0, math)
-    run("caustic", 64, 48, 8, 0, math)
-    run("materials", 64, 48, 4, 0, math)
-    run("materials", 64, 48, 4, 1, math)
-    run("obj-model", 32, 24, 2, 0, math)
-    run("cornell", 32, 24, 2, 0, math)
-    run("complex", 32, 24, 2, 0, math)
+        run("cornell-large", 64, 48, 4, 0, math, K, lds=lds)
+    run("simple", 64, 48, 4, 0, math, K)
+    run("caustic", 64, 48, 8, 0, math, K)
+    run("materials", 64, 48, 4, 0, math, K)
+    run("materials", 64, 48, 4, 1, math, K)
+    run("obj-model", 32, 24, 2, 0, math, K)
+    run("cornell", 32, 24, 2, 0, math, K)
+    run("cornell", 37, 21, 2, 0, math, K, lds=0)
+    run("complex", 32, 24, 2, 0, math, K)
 sc = pt.LoadedScene("cornell", 1024, 768); seeds = pt.seed_block(1024, 768)
-for math in (pt.MATH_STRICT, pt.MATH_FAST):
-    g = pt.Gpu(0, 0, kernel=pt.KERNEL_MEGA, math=math); g.set_scene(sc); g.resize(1024, 768, seeds)
-    g.render_timed(1)
-    ms = g.render_timed(2)
-    print("cornell 1024x768 mega math", math, "ms/pass", ms / 2, "Mpaths/s", 1024 * 768 * 2 / ms / 1e3, flush=True)
-    g.close()
+for kernel in (pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT):
+  for math in (pt.MATH_STRICT, pt.MATH_FAST):
+    for lds in (1, 0):
+        g = pt.Gpu(0, 0, kernel=kernel, math=math, lds=lds); g.set_scene(sc); g.resize(1024, 768, seeds)
+        g.render_timed(1)
+        ms = g.render_timed(4)
+        print("cornell 1024x768 kernel", kernel, "math", math, "lds", lds, "ms/pass", ms / 4, "Mpaths/s", 1024 * 768 * 4 / ms / 1e3, flush=True)
+        g.close()

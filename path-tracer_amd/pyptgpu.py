@@ -278,7 +278,8 @@ class Gpu:
 
     def resize(self, w, h, seeds):
         seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
-        assert seeds.size == 2 * w * h
+        if w > 0 and h > 0 and seeds.size != 2 * w * h:
+            raise ValueError('seeds must hold 2*W*H words')
         self._ok(self.lib.ptgpu_resize(self.ctx, w, h, _ptr(seeds)))
         self.w, self.h, self.sample = w, h, 0
 

@@ -39,8 +39,13 @@ enum {
 enum {
     PTGPU_OPT_KERNEL = 0, /* PTGPU_KERNEL_*  (default WAVEFRONT)                        */
     PTGPU_OPT_MATH   = 1, /* PTGPU_MATH_*    (default FAST)                             */
-    PTGPU_OPT_LDS    = 2  /* 1 = stage primitive/light records in LDS (default), 0 = read them
+    PTGPU_OPT_LDS    = 2, /* 1 = stage primitive/light records in LDS (default), 0 = read them
                              with wave-uniform (scalar) loads from global memory        */
+    PTGPU_OPT_STREAMS = 3, /* 1..4 image regions rendered on concurrent HIP streams (default 4):
+                              one region's launch tail overlaps the other regions' work.  All
+                              work is still ordered on the context's stream (fork/join events) */
+    PTGPU_OPT_PASSES_PER_LAUNCH = 4, /* passes looped inside one kernel launch; 0 = automatic */
+    PTGPU_OPT_WAVES_PER_GROUP = 5    /* wavefront kernel: waves per workgroup, 1..16; 0 = default */
 };
 enum {
     PTGPU_KERNEL_MEGA      = 0, /* one thread = one pixel = one whole path; the direct counterpart of

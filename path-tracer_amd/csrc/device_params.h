@@ -36,11 +36,15 @@ struct PtDeviceParams {
     uint32_t *seeds;      // 2 words per pixel at y*W+x
     int tiles_x;          // image width in 8x8 pixel tiles (one wave = one tile)
     int n_tiles;
+    // this launch covers tiles tile_first + k * tile_stride, k in [0, n_launch_tiles): the image is
+    // dealt round-robin into regions so independent regions can run on concurrent streams
+    int tile_first, tile_stride, n_launch_tiles;
 };
 
 struct PtLaunchConfig {
     int use_lds;          // stage prims+lights in LDS
     unsigned lds_bytes;   // dynamic LDS for the staged records
+    int waves_per_group;  // wavefront kernel: waves per workgroup (0 = default)
 };
 
 namespace ptk_fast {

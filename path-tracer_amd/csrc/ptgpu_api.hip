@@ -37,6 +37,11 @@ int fail(int code, const char *fmt, ...) {
 // records with wave-uniform loads from global memory instead (160 KiB per CU on gfx950).
 constexpr unsigned kMaxStagedLdsBytes = 96 * 1024; // + 58 KiB of per-wave scratch in the wavefront kernel
 
+// Regions of the image rendered on concurrent streams (the context's own stream is one of them):
+// while one region's launch drains its last waves, the other regions' launches keep the CUs full.
+// 4 = HIP's default number of hardware queues per process (GPU_MAX_HW_QUEUES).
+constexpr int kMaxStreams = 4;
+
 bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 0.f)); } // vec.h:23
 
 } // namespace
@@ -47,7 +52,12 @@ struct ptgpu_ctx {
     int kernel = PTGPU_KERNEL_WAVEFRONT;
     int math = PTGPU_MATH_FAST;
     int want_lds = 1;
-    hipStream_t stream = nullptr;
+    int n_streams = kMaxStreams;      // regions rendered concurrently (PTGPU_OPT_STREAMS)
+    int passes_per_launch = 0;        // 0 = automatic (PTGPU_OPT_PASSES_PER_LAUNCH)
+    int waves_per_group = 0;          // 0 = default (PTGPU_OPT_WAVES_PER_GROUP)
+    hipStream_t stream = nullptr;     // the context's stream: everything is ordered on it
+    hipStream_t side[kMaxStreams - 1] = {};
+    hipEvent_t fork_ev = nullptr, join_ev[kMaxStreams - 1] = {};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // scene
@@ -128,6 +138,9 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.seeds = c->d_seeds;
     p.tiles_x = (c->width + 7) / 8;
     p.n_tiles = p.tiles_x * ((c->height + 7) / 8);
+    p.tile_first = 0;
+    p.tile_stride = 1;
+    p.n_launch_tiles = p.n_tiles;
     return p;
 }
 
@@ -140,20 +153,42 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     PtLaunchConfig cfg{};
     cfg.use_lds = c->want_lds && c->info.lds_bytes > 0;
     cfg.lds_bytes = cfg.use_lds ? c->info.lds_bytes : 0;
-    // keep each launch short enough to stay preemptible: passes are chunked
-    const int chunk = 8;
+    cfg.waves_per_group = c->waves_per_group;
+    PtDeviceParams probe = make_params(c, first_sample, 1);
+    // One region per stream when the image has enough tiles to keep every region's launch wide.
+    const int regions = (c->n_streams > 1 && probe.n_tiles >= 2048) ? c->n_streams : 1;
+    // Passes done inside one launch: with several regions in flight a launch may be short (its
+    // tail is covered by the other regions); a single region keeps 8 passes per launch.
+    const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);
+
+    auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
+        if (c->kernel == PTGPU_KERNEL_MEGA)
+            return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);
+        return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_wavefront(p, cfg, s)
+                                            : ptk_fast::launch_wavefront(p, cfg, s);
+    };
+
+    if (regions > 1) { // fork: side streams start after everything already queued on the main one
+        HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
+        for (int r = 1; r < regions; ++r) HIP_TRY(hipStreamWaitEvent(c->side[r - 1], c->fork_ev, 0));
+    }
     for (int done = 0; done < n_passes; done += chunk) {
         const int n = (n_passes - done < chunk) ? n_passes - done : chunk;
-        const PtDeviceParams p = make_params(c, first_sample + done, n);
-        int rc;
-        if (c->kernel == PTGPU_KERNEL_MEGA)
-            rc = c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_mega(p, cfg, c->stream)
-                                              : ptk_fast::launch_mega(p, cfg, c->stream);
-        else
-            rc = c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_wavefront(p, cfg, c->stream)
-                                              : ptk_fast::launch_wavefront(p, cfg, c->stream);
-        if (rc != 0)
-            return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        for (int r = 0; r < regions; ++r) {
+            PtDeviceParams p = make_params(c, first_sample + done, n);
+            p.tile_first = r;
+            p.tile_stride = regions;
+            p.n_launch_tiles = (p.n_tiles - r + regions - 1) / regions;
+            const int rc = launch(p, r == 0 ? c->stream : c->side[r - 1]);
+            if (rc != 0)
+                return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        }
+    }
+    if (regions > 1) { // join: the main stream continues only after every region is done
+        for (int r = 1; r < regions; ++r) {
+            HIP_TRY(hipEventRecord(c->join_ev[r - 1], c->side[r - 1]));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev[r - 1], 0));
+        }
     }
     return PTGPU_OK;
 }
@@ -189,6 +224,11 @@ int ptgpu_create(ptgpu_ctx **out, int device_ordinal, int integrator) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+    for (int i = 0; i < kMaxStreams - 1; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+    }
     *out = c;
     return PTGPU_OK;
 }
@@ -199,6 +239,12 @@ int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_scene(ctx);
     free_image(ctx);
+    for (int i = 0; i < kMaxStreams - 1; ++i) {
+        if (ctx->side[i]) (void)hipStreamSynchronize(ctx->side[i]);
+        if (ctx->side[i]) (void)hipStreamDestroy(ctx->side[i]);
+        if (ctx->join_ev[i]) (void)hipEventDestroy(ctx->join_ev[i]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -221,6 +267,19 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         return PTGPU_OK;
     case PTGPU_OPT_LDS:
         ctx->want_lds = value ? 1 : 0;
+        return PTGPU_OK;
+    case PTGPU_OPT_STREAMS:
+        if (value < 1 || value > kMaxStreams)
+            return fail(PTGPU_ERR_ARGUMENT, "streams must be 1..%d", kMaxStreams);
+        ctx->n_streams = value;
+        return PTGPU_OK;
+    case PTGPU_OPT_WAVES_PER_GROUP:
+        if (value < 0 || value > 16) return fail(PTGPU_ERR_ARGUMENT, "waves per group must be 0..16");
+        ctx->waves_per_group = value;
+        return PTGPU_OK;
+    case PTGPU_OPT_PASSES_PER_LAUNCH:
+        if (value < 0 || value > 64) return fail(PTGPU_ERR_ARGUMENT, "passes per launch must be 0..64");
+        ctx->passes_per_launch = value;
         return PTGPU_OK;
     default:
         return fail(PTGPU_ERR_ARGUMENT, "unknown option %d", option);

@@ -190,7 +190,7 @@ def obj_parse(data: bytes):
 # ---------------------------------------------------------------------------------------------
 # libptgpu.so (HIP).  No fallback: a missing library or a missing GPU raises.
 # ---------------------------------------------------------------------------------------------
-OPT_KERNEL, OPT_MATH, OPT_LDS = 0, 1, 2
+OPT_KERNEL, OPT_MATH, OPT_LDS, OPT_STREAMS, OPT_PASSES_PER_LAUNCH, OPT_WAVES_PER_GROUP = 0, 1, 2, 3, 4, 5
 KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
@@ -247,7 +247,8 @@ def gpu():
 class Gpu:
     """One ptgpu context driven the way main-gpu.c drives its OpenCL objects."""
 
-    def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None):
+    def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None, streams=None,
+                 passes_per_launch=None, waves_per_group=None):
         self.lib = gpu()
         self.ctx = C.c_void_p()
         self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
@@ -257,6 +258,12 @@ class Gpu:
             self.set_option(OPT_MATH, math)
         if lds is not None:
             self.set_option(OPT_LDS, lds)
+        if streams is not None:
+            self.set_option(OPT_STREAMS, streams)
+        if passes_per_launch is not None:
+            self.set_option(OPT_PASSES_PER_LAUNCH, passes_per_launch)
+        if waves_per_group is not None:
+            self.set_option(OPT_WAVES_PER_GROUP, waves_per_group)
         self.w = self.h = 0
         self.sample = 0
 

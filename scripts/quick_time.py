@@ -14,12 +14,11 @@ for name, w, h, spp in (("cornell", 40, 24, 2), ("materials", 64, 48, 3), ("obj-
 scenes = sys.argv[1:] or ["cornell"]
 for scn in scenes:
     sc = pt.LoadedScene(scn, 1024, 768); seeds = pt.seed_block(1024, 768)
-    for kernel in (0, 1):
-        for math in (0, 1):
-            g = pt.Gpu(0, 0, kernel=kernel, math=math); g.set_scene(sc); g.resize(1024, 768, seeds)
-            n = 8 if scn in ("cornell", "obj-model", "large-object") else 64
+    for kernel, math, streams, ppl in ((0, 0, 1, 8), (0, 0, 4, 1), (1, 1, 4, 1), (1, 0, 1, 8), (1, 0, 2, 1), (1, 0, 4, 1), (1, 0, 4, 2), (1, 0, 3, 1)):
+            g = pt.Gpu(0, 0, kernel=kernel, math=math, streams=streams, passes_per_launch=ppl); g.set_scene(sc); g.resize(1024, 768, seeds)
+            n = 16 if scn in ("cornell", "obj-model", "large-object") else 64
             g.render_timed(n)
             ms = min(g.render_timed(n) for _ in range(2))
-            print(f"{scn} 1024x768 kernel {'wavefront' if kernel else 'mega'} math {'strict' if math else 'fast'}: "
+            print(f"{scn} 1024x768 kernel {'wavefront' if kernel else 'mega'} math {'strict' if math else 'fast'} streams {streams} passes/launch {ppl}: "
                   f"{ms / n:.2f} ms/pass  {1024 * 768 * n / ms / 1e3:.2f} Mpaths/s", flush=True)
             g.close()

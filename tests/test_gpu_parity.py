@@ -261,3 +261,30 @@ def test_full_size_properties_cornell_1024x768():
         assert (ss[y, x] == (a.value, b.value)).all()
     for q in (g, g2, gs):
         q.close()
+
+
+def test_c_host_cli_end_to_end(tmp_path):
+    """The headless C host (ptcli = main-gpu.c's main()/updateRendering() over the C-ABI) renders a
+    scene file to a PPM whose bytes are the oracle's packed pixels (strict build), rows bottom-up
+    as the reference's 'p' key writes them (displayfunc.c:508-515)."""
+    import os
+    import subprocess
+    from conftest import REPO
+    out = tmp_path / "img.ppm"
+    w, h, spp = 56, 40, 23          # crosses the 20-sample switch of the adaptive schedule
+    cmd = [os.path.join(REPO, "path-tracer_amd", "ptcli"), "1", "0", "ray-tracing.cl", str(w), str(h),
+           os.path.join(REPO, "data", "scenes", "materials.txt"), "--spp", str(spp), "--math", "strict",
+           "--models", os.path.join(REPO, "data"), "--out", str(out), "--quiet"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "materials: %d passes, %dx%d" % (spp, w, h) in r.stdout
+    tok = out.read_text().split()
+    assert tok[:4] == ["P3", str(w), str(h), "255"]
+    rgb = np.array(tok[4:], dtype=np.uint32).reshape(h, w, 3)[::-1]      # file is bottom-up
+    sc = pt.LoadedScene("materials", w, h)
+    cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 1).pass_oracle(spp, threads=8)
+    want = cpu.pixels.reshape(h, w)
+    assert ((rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16)) == (want & 0xffffff)).all()
+    # bad arguments: print-and-exit(-1) like the reference
+    bad = subprocess.run(cmd[:6] + ["/nonexistent.txt"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "Failed to open file" in bad.stderr

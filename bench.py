@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
+    ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4)")
+    ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -100,7 +102,8 @@ def main():
     seeds = pt.seed_block(w, h, rank)
     g = pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
                kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
-               math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT)
+               math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT, streams=args.streams,
+               passes_per_launch=args.passes_per_launch)
     g.set_scene(sc)
     g.resize(w, h, seeds)
     colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * w * h),
@@ -139,17 +142,28 @@ def main():
         baseline, flops_per_path, counters = (None, None, None)
         if world == 1 and not args.no_cpu:
             baseline, flops_per_path, counters = cpu_baseline(args.scene)
-        avg_launch_ms = sum(launch_ms) / len(launch_ms)
+        # One step = args.passes passes.  With S region streams a pass is S concurrent launches of
+        # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the
+        # library's stream (fork/join), so the per-launch figure below is step time / sequential
+        # launch groups, and rocprof's per-launch AverageNs is about S x larger than
+        # avg_launch_group_ms / 1 because the S launches overlap (see DESIGN.md "Measurement").
+        avg_step_ms = sum(launch_ms) / len(launch_ms)
+        ppl = args.passes_per_launch or (1 if (args.streams > 1 and ((w + 7) // 8) * ((h + 7) // 8) >= 2048) else 8)
+        groups_per_step = (args.passes + ppl - 1) // ppl
         roofline = None
         if flops_per_path is not None:
-            achieved = flops_per_path * paths_per_launch / (avg_launch_ms * 1e-3) / 1e12
+            achieved = flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12
             roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                         "kernel": f"radiance_{args.kernel}_kernel ({args.math})",
-                        "avg_launch_ms": avg_launch_ms,
+                        "avg_step_event_ms": avg_step_ms,
+                        "avg_launch_group_ms": avg_step_ms / groups_per_step,
+                        "launch_groups_per_step": groups_per_step,
+                        "concurrent_launches_per_group": args.streams if ppl == 1 or args.streams > 1 else 1,
+                        "passes_per_launch": ppl,
                         "algorithmic_flops_per_path": flops_per_path,
-                        "paths_per_launch": paths_per_launch,
-                        "hbm_algorithmic_bytes_per_launch": 44 * w * h}
+                        "paths_per_step": paths_per_launch,
+                        "hbm_algorithmic_bytes_per_pass": 44 * w * h}
         line = {
             "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
     ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4)")
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
+    ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
@@ -91,11 +92,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the radiance path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()  # rehearsals may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     w, h = args.width, args.height
     sc = pt.LoadedScene(args.scene, w, h)

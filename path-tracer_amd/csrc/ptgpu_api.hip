@@ -156,7 +156,10 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     cfg.waves_per_group = c->waves_per_group;
     PtDeviceParams probe = make_params(c, first_sample, 1);
     // One region per stream when the image has enough tiles to keep every region's launch wide.
-    const int regions = (c->n_streams > 1 && probe.n_tiles >= 2048) ? c->n_streams : 1;
+    // Cheap scenes (a pass is tens of microseconds) gain nothing from overlapping tails and lose to
+    // the extra launches, so they stay on one stream with the passes looped inside the launch.
+    const long long work = (long long)c->info.primitives * (1 + (long long)c->info.lights);
+    const int regions = (c->n_streams > 1 && probe.n_tiles >= 2048 && work >= 128) ? c->n_streams : 1;
     // Passes done inside one launch: with several regions in flight a launch may be short (its
     // tail is covered by the other regions); a single region keeps 8 passes per launch.
     const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);

@@ -215,7 +215,7 @@ def gpu():
     """libptgpu.so, loaded once.  Raises if the HIP extension has not been built."""
     global _gpu
     if _gpu is None:
-        path = os.path.join(HERE, "libptgpu.so")
+        path = os.environ.get("PTGPU_LIB") or os.path.join(HERE, "libptgpu.so")  # PTGPU_LIB: A/B builds
         if not os.path.exists(path):
             raise GpuError("libptgpu.so is missing: build it with `make -C path-tracer_amd/csrc` "
                            "(there is no CPU fallback for the radiance path)")

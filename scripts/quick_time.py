@@ -14,7 +14,7 @@ for name, w, h, spp in (("cornell", 40, 24, 2), ("materials", 64, 48, 3), ("obj-
 scenes = sys.argv[1:] or ["cornell"]
 for scn in scenes:
     sc = pt.LoadedScene(scn, 1024, 768); seeds = pt.seed_block(1024, 768)
-    for kernel, math, streams, ppl in ((0, 0, 1, 8), (0, 0, 4, 1), (1, 1, 4, 1), (1, 0, 1, 8), (1, 0, 2, 1), (1, 0, 4, 1), (1, 0, 4, 2), (1, 0, 3, 1)):
+    for kernel, math, streams, ppl in ((0, 0, 4, 1), (1, 1, 4, 1), (1, 0, 1, 8), (1, 0, 4, 1)):
             g = pt.Gpu(0, 0, kernel=kernel, math=math, streams=streams, passes_per_launch=ppl); g.set_scene(sc); g.resize(1024, 768, seeds)
             n = 16 if scn in ("cornell", "obj-model", "large-object") else 64
             g.render_timed(n)

@@ -88,6 +88,18 @@ void pthost_captions(char *line1, char *line2, size_t len, double elapsed_total,
  * (0 means "exactly one pass"). */
 float pthost_frame_time_budget(int current_sample);
 
+/* Checkpoint / resume (no reference counterpart - the reference's resumable state
+ * is exactly these three things, main-gpu.c:23-25, 40): the running-mean colour buffer
+ * [(H-1-y)*W+x], the per-pixel RNG state [2*(y*W+x)] and the sample counter.  The file is
+ * "PTCKPT01", int32 width, height, current_sample, then 12*W*H bytes of colours and 8*W*H bytes of
+ * seeds, little endian.  Resume = ptgpu_resize(w, h, seeds) + ptgpu_write_colors(colors) and
+ * continue at current_sample: the continued render is bit-identical to an uninterrupted one.
+ * pthost_checkpoint_read malloc()s *colors and *seeds. */
+int pthost_checkpoint_write(const char *path, int width, int height, int current_sample,
+                            const float *colors, const uint32_t *seeds);
+int pthost_checkpoint_read(const char *path, int *width, int *height, int *current_sample,
+                           float **colors, uint32_t **seeds);
+
 const char *pthost_last_error(void);
 
 #ifdef __cplusplus

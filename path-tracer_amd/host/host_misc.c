@@ -166,3 +166,67 @@ float pthost_frame_time_budget(int current_sample) {
     const float k = (d < 100 ? d : 100) / 100.f;
     return 0.5f * k;
 }
+
+/* ---- checkpoint / resume (no reference counterpart; format in pthost.h) ---- */
+static const char kCkptMagic[8] = {'P', 'T', 'C', 'K', 'P', 'T', '0', '1'};
+
+int pthost_checkpoint_write(const char *path, int width, int height, int current_sample,
+                            const float *colors, const uint32_t *seeds) {
+    if (!path || !colors || !seeds || width <= 0 || height <= 0 || current_sample < 0) {
+        pthost_set_error("checkpoint: bad argument");
+        return -1;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        pthost_set_error("checkpoint: cannot create '%s'", path);
+        return -1;
+    }
+    const int32_t hdr[3] = {width, height, current_sample};
+    const size_t n = (size_t)width * height;
+    int ok = fwrite(kCkptMagic, 1, 8, f) == 8 && fwrite(hdr, sizeof hdr, 1, f) == 1 &&
+             fwrite(colors, 12, n, f) == n && fwrite(seeds, 8, n, f) == n;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        pthost_set_error("checkpoint: short write to '%s'", path);
+        return -1;
+    }
+    return 0;
+}
+
+int pthost_checkpoint_read(const char *path, int *width, int *height, int *current_sample,
+                           float **colors, uint32_t **seeds) {
+    if (!path || !width || !height || !current_sample || !colors || !seeds) {
+        pthost_set_error("checkpoint: bad argument");
+        return -1;
+    }
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        pthost_set_error("checkpoint: cannot open '%s'", path);
+        return -1;
+    }
+    char magic[8];
+    int32_t hdr[3];
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, kCkptMagic, 8) != 0 || fread(hdr, sizeof hdr, 1, f) != 1 ||
+        hdr[0] <= 0 || hdr[1] <= 0 || hdr[2] < 0 || (long long)hdr[0] * hdr[1] > (1ll << 28)) {
+        fclose(f);
+        pthost_set_error("checkpoint: '%s' is not a PTCKPT01 file", path);
+        return -1;
+    }
+    const size_t n = (size_t)hdr[0] * hdr[1];
+    float *c = (float *)malloc(12 * n);
+    uint32_t *s = (uint32_t *)malloc(8 * n);
+    if (!c || !s || fread(c, 12, n, f) != n || fread(s, 8, n, f) != n) {
+        fclose(f);
+        free(c);
+        free(s);
+        pthost_set_error("checkpoint: '%s' is truncated", path);
+        return -1;
+    }
+    fclose(f);
+    *width = hdr[0];
+    *height = hdr[1];
+    *current_sample = hdr[2];
+    *colors = c;
+    *seeds = s;
+    return 0;
+}

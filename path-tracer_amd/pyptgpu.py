@@ -97,6 +97,10 @@ def host():
         lib.pthost_captions.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, C.c_double, C.c_double,
                                         C.c_int, C.c_int, C.c_int, C.c_int]
         lib.pthost_captions.restype = None
+        lib.pthost_checkpoint_write.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.pthost_checkpoint_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                               C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_float)),
+                                               C.POINTER(C.POINTER(C.c_uint32))]
         lib.pthost_frame_time_budget.argtypes = [C.c_int]
         lib.pthost_frame_time_budget.restype = C.c_float
         _host = lib
@@ -175,6 +179,29 @@ def obj_load(path):
     if rc != 0:
         raise HostError(host().pthost_last_error().decode())
     return _take_obj(v, nv, idx, nc, nf)
+
+
+def checkpoint_write(path, width, height, sample, colors, seeds):
+    colors = np.ascontiguousarray(colors, dtype=np.float32)
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+    if host().pthost_checkpoint_write(path.encode(), width, height, sample, _ptr(colors), _ptr(seeds)) != 0:
+        raise HostError(host().pthost_last_error().decode())
+
+
+def checkpoint_read(path):
+    w, h, k = C.c_int(), C.c_int(), C.c_int()
+    c = C.POINTER(C.c_float)()
+    s = C.POINTER(C.c_uint32)()
+    if host().pthost_checkpoint_read(path.encode(), C.byref(w), C.byref(h), C.byref(k), C.byref(c), C.byref(s)) != 0:
+        raise HostError(host().pthost_last_error().decode())
+    n = w.value * h.value
+    colors = np.ctypeslib.as_array(c, shape=(n, 3)).copy()
+    seeds = np.ctypeslib.as_array(s, shape=(2 * n,)).copy()
+    libc = C.CDLL(None)
+    libc.free.argtypes = [C.c_void_p]
+    libc.free(c)
+    libc.free(s)
+    return w.value, h.value, k.value, colors, seeds
 
 
 def obj_parse(data: bytes):

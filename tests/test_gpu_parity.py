@@ -288,3 +288,70 @@ def test_c_host_cli_end_to_end(tmp_path):
     # bad arguments: print-and-exit(-1) like the reference
     bad = subprocess.run(cmd[:6] + ["/nonexistent.txt"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "Failed to open file" in bad.stderr
+
+
+def test_checkpoint_resume_is_bit_identical(tmp_path):
+    w, h = 48, 32
+    sc = pt.LoadedScene("materials", w, h)
+    seeds = pt.seed_block(w, h)
+    for math in (pt.MATH_STRICT, pt.MATH_FAST):
+        straight = pt.Gpu(0, 0, math=math)
+        straight.set_scene(sc)
+        straight.resize(w, h, seeds)
+        straight.render(8)
+        a = pt.Gpu(0, 0, math=math)
+        a.set_scene(sc)
+        a.resize(w, h, seeds)
+        a.render(5)
+        ck = str(tmp_path / "r.ckpt")
+        pt.checkpoint_write(ck, w, h, a.sample, a.colors(), a.seeds())
+        a.close()
+        w2, h2, k, colors, sd = pt.checkpoint_read(ck)
+        b = pt.Gpu(0, 0, math=math)
+        b.set_scene(sc)
+        b.resize(w2, h2, sd)
+        b.write_colors(colors)
+        b.sample = k
+        b.render(3)
+        assert same_bits(b.colors(), straight.colors()) and (b.seeds() == straight.seeds()).all()
+        assert (b.pixels() == straight.pixels()).all()
+        b.close()
+        straight.close()
+
+
+def test_config5_cornell_large_4k_properties():
+    """BASELINE.json config 5's per-GPU shape: cornell-large at 3840x2160 (8.3 M pixels, 199 MB of
+    image state), checked through size-independent properties and strict-build oracle spot checks."""
+    import ctypes as C
+    w, h = 3840, 2160
+    sc = pt.LoadedScene("cornell-large", w, h)
+    seeds = pt.seed_block(w, h, rank=3)                       # a non-zero rank's seed block
+    g = pt.Gpu(0, 0, math=pt.MATH_STRICT)
+    g.set_scene(sc)
+    g.resize(w, h, seeds)
+    g.render(2)
+    cs, ss, px = g.colors().reshape(h, w, 3), g.seeds().reshape(h, w, 2), g.pixels().reshape(h, w)
+    assert np.isfinite(cs).all() and (cs >= 0).all()
+    rng = np.random.default_rng(11)
+    pts = [(0, 0), (w - 1, h - 1), (w - 1, 0), (0, h - 1)] + [(int(rng.integers(0, w)), int(rng.integers(0, h))) for _ in range(20)]
+    for x, y in pts:
+        a, b = C.c_uint32(int(seeds[2 * (y * w + x)])), C.c_uint32(int(seeds[2 * (y * w + x) + 1]))
+        col = pt.Vec3(0, 0, 0)
+        for k in range(2):
+            ray, rad = pt.Ray(), pt.Vec3()
+            ob.oracle().oracle_camera_ray(C.byref(sc.camera), x, y, w, h, C.byref(a), C.byref(b), C.byref(ray))
+            ob.oracle().oracle_radiance(sc.objects.ctypes.data_as(C.c_void_p), sc.object_count, sc.light_count,
+                                        C.byref(ray), C.byref(a), C.byref(b), C.byref(sc.scene),
+                                        sc.materials.ctypes.data_as(C.c_void_p), 0, C.byref(rad))
+            pixel = ob.oracle().oracle_accumulate(C.byref(col), C.byref(rad), k, sc.scene.gamma)
+        assert same_bits(np.array(col.tuple(), np.float32), cs[h - 1 - y, x])
+        assert (ss[y, x] == (a.value, b.value)).all() and px[y, x] == pixel
+    # the fast build on the same frame: same RNG state on >= 99.9 % of the pixels after 2 passes
+    f = pt.Gpu(0, 0, math=pt.MATH_FAST)
+    f.set_scene(sc)
+    f.resize(w, h, seeds)
+    f.render(2)
+    agree = (f.seeds().reshape(-1, 2) == ss.reshape(-1, 2)).all(1).mean()
+    assert agree > 0.999, agree
+    g.close()
+    f.close()

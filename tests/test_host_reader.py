@@ -204,3 +204,24 @@ def test_frame_budget_schedule():
     f = pt.host().pthost_frame_time_budget
     assert f(0) == 0 and f(19) == 0 and f(20) == 0
     assert abs(f(70) - 0.25) < 1e-7 and abs(f(120) - 0.5) < 1e-7 and abs(f(5000) - 0.5) < 1e-7
+
+
+def test_checkpoint_roundtrip_and_errors(tmp_path):
+    rng = np.random.default_rng(5)
+    w, h = 7, 5
+    colors = rng.random((w * h, 3), dtype=np.float32)
+    colors[3] = np.nan                                   # NaN pixels survive a checkpoint
+    seeds = rng.integers(2, 2**32, 2 * w * h, dtype=np.uint32)
+    p = str(tmp_path / "c.ckpt")
+    pt.checkpoint_write(p, w, h, 41, colors, seeds)
+    assert os.path.getsize(p) == 8 + 12 + 12 * w * h + 8 * w * h
+    w2, h2, k, c2, s2 = pt.checkpoint_read(p)
+    assert (w2, h2, k) == (w, h, 41) and c2.tobytes() == colors.tobytes() and (s2 == seeds).all()
+    open(p, "r+b").truncate(100)
+    with pytest.raises(pt.HostError, match="truncated"):
+        pt.checkpoint_read(p)
+    (tmp_path / "x").write_bytes(b"not a checkpoint at all....")
+    with pytest.raises(pt.HostError, match="PTCKPT01"):
+        pt.checkpoint_read(str(tmp_path / "x"))
+    with pytest.raises(pt.HostError):
+        pt.checkpoint_read(str(tmp_path / "missing"))

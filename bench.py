@@ -155,11 +155,21 @@ def main():
         avg_step_ms = sum(launch_ms) / len(launch_ms)
         ppl = args.passes_per_launch or (1 if (args.streams > 1 and ((w + 7) // 8) * ((h + 7) // 8) >= 2048) else 8)
         groups_per_step = (args.passes + ppl - 1) // ppl
+        # HBM bytes per pass from the committed PMC run of this workload (separate rocprofv3 --pmc
+        # passes, profiles/traffic.json); null for any other workload.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
+            if (args.scene, w, h, args.kernel, args.math) == ("cornell", 1024, 768, "wavefront", "fast"):
+                traffic = tj["bytes_per_pass"] * args.passes
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = None
         if flops_per_path is not None:
             achieved = flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12
             roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE + WRITE_SIZE), algorithmic %d" % (44 * w * h * args.passes),
                         "kernel": f"radiance_{args.kernel}_kernel ({args.math})",
                         "avg_step_event_ms": avg_step_ms,
                         "avg_launch_group_ms": avg_step_ms / groups_per_step,

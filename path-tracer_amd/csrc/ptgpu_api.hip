@@ -171,6 +171,7 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
                                             : ptk_fast::launch_wavefront(p, cfg, s);
     };
 
+    int launch_error = 0;
     if (regions > 1) { // fork: side streams start after everything already queued on the main one
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
         for (int r = 1; r < regions; ++r) HIP_TRY(hipStreamWaitEvent(c->side[r - 1], c->fork_ev, 0));
@@ -183,9 +184,9 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
             p.tile_stride = regions;
             p.n_launch_tiles = (p.n_tiles - r + regions - 1) / regions;
             const int rc = launch(p, r == 0 ? c->stream : c->side[r - 1]);
-            if (rc != 0)
-                return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            if (rc != 0 && launch_error == 0) launch_error = rc;
         }
+        if (launch_error) break;
     }
     if (regions > 1) { // join: the main stream continues only after every region is done
         for (int r = 1; r < regions; ++r) {
@@ -193,6 +194,8 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->join_ev[r - 1], 0));
         }
     }
+    if (launch_error)
+        return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)launch_error));
     return PTGPU_OK;
 }
 
@@ -224,13 +227,24 @@ int ptgpu_create(ptgpu_ctx **out, int device_ordinal, int integrator) {
     if (!c) return fail(PTGPU_ERR_MEMORY, "out of host memory");
     c->device = device_ordinal;
     c->integrator = integrator;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
-    for (int i = 0; i < kMaxStreams - 1; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+    auto make_queues = [&]() -> int {
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming));
+        for (int i = 0; i < kMaxStreams - 1; ++i) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->join_ev[i], hipEventDisableTiming));
+        }
+        return PTGPU_OK;
+    };
+    const int rc = make_queues();
+    if (rc != PTGPU_OK) {
+        char keep[sizeof g_error];
+        memcpy(keep, g_error, sizeof keep);
+        (void)ptgpu_destroy(c); // releases whatever was created
+        memcpy(g_error, keep, sizeof keep);
+        return rc;
     }
     *out = c;
     return PTGPU_OK;

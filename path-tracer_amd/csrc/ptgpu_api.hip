@@ -49,7 +49,7 @@ bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 
 struct ptgpu_ctx {
     int device = 0;
     int integrator = PT_INTEGRATOR_PT;
-    int kernel = PTGPU_KERNEL_WAVEFRONT;
+    int kernel = PTGPU_KERNEL_AUTO;
     int math = PTGPU_MATH_FAST;
     int want_lds = 1;
     int n_streams = kMaxStreams;      // regions rendered concurrently (PTGPU_OPT_STREAMS)
@@ -164,8 +164,10 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     // tail is covered by the other regions); a single region keeps 8 passes per launch.
     const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);
 
+    const int kernel = c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
+                       : (c->info.lights >= 2 ? PTGPU_KERNEL_WAVEFRONT : PTGPU_KERNEL_MEGA);
     auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
-        if (c->kernel == PTGPU_KERNEL_MEGA)
+        if (kernel == PTGPU_KERNEL_MEGA)
             return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);
         return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_wavefront(p, cfg, s)
                                             : ptk_fast::launch_wavefront(p, cfg, s);
@@ -273,7 +275,7 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
     if (!ctx) return fail(PTGPU_ERR_ARGUMENT, "null context");
     switch (option) {
     case PTGPU_OPT_KERNEL:
-        if (value != PTGPU_KERNEL_MEGA && value != PTGPU_KERNEL_WAVEFRONT)
+        if (value != PTGPU_KERNEL_MEGA && value != PTGPU_KERNEL_WAVEFRONT && value != PTGPU_KERNEL_AUTO)
             return fail(PTGPU_ERR_ARGUMENT, "unknown kernel variant %d", value);
         ctx->kernel = value;
         return PTGPU_OK;

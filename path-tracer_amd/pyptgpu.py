@@ -218,7 +218,7 @@ def obj_parse(data: bytes):
 # libptgpu.so (HIP).  No fallback: a missing library or a missing GPU raises.
 # ---------------------------------------------------------------------------------------------
 OPT_KERNEL, OPT_MATH, OPT_LDS, OPT_STREAMS, OPT_PASSES_PER_LAUNCH, OPT_WAVES_PER_GROUP = 0, 1, 2, 3, 4, 5
-KERNEL_MEGA, KERNEL_WAVEFRONT = 0, 1
+KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
 

@@ -10,9 +10,12 @@ ranks.  With N > 1 each rank renders from its own seed block and the colour buff
 one RCCL all-reduce inside the timed region (weak scaling: per-GPU work is fixed).
 
 The JSON line also carries
-  roofline     FP32 VALU: reference-equivalent flops F per path (counted by the CPU
-               oracle on a sample of the same scene) x paths per launch / average launch duration
-               from HIP events on the library's stream, against 157.3 TFLOP/s.
+  roofline     FP32 VALU: algorithmic flops F per path x paths per launch / average
+               launch duration from HIP events on the library's stream, against 157.3 TFLOP/s.  F is
+               counted by the CPU oracle on a sample of the same scene while it replays the product's
+               shadow-ray candidate sets (the tests the algorithm the kernel runs has to make);
+               the reference's brute-force count is reported beside it as reference_equivalent_*
+               and is NOT what `achieved` is built from.
   cpu_baseline the CPU oracle (a bit-exact port of the reference's main-cpu.c path) timed on this
                host's cores on a bounded sample of the same scene.
 """
@@ -28,7 +31,7 @@ sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 x 2.4 GHz
 
 
-def cpu_baseline(scene_name):
+def cpu_baseline(scene_name, cull_mode):
     """Rank 0, N = 1 only.  oracle/ is used here as the timed CPU baseline and the flop counter."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_binding as ob
@@ -42,6 +45,11 @@ def cpu_baseline(scene_name):
     ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle_counted(ctr, 1)
     t_count = time.perf_counter() - t0
     flops_per_path = ctr.flops() / ctr.paths
+    # the same count with the shadow-ray candidate sets the kernel uses (same image under SAFE)
+    culled = ob.Counters()
+    with ob.shadow_candidates(pt.shadow_candidates(sc, cull_mode)):
+        ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle_counted(culled, 1)
+    culled_flops_per_path = culled.flops() / culled.paths
     # single thread = the reference's serial loop (main-cpu.c:61-62)
     t0 = time.perf_counter()
     ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle(1, threads=1)
@@ -60,7 +68,7 @@ def cpu_baseline(scene_name):
         "sample": f"{scene_name} {bw}x{bh} x 1 spp, {threads} OpenMP threads over rows, {t_all:.1f} s",
         "single_thread_value": one,
         "single_thread_sample": f"{scene_name} {cw}x{ch} x 1 spp, serial loop as main-cpu.c, {t_one:.1f} s",
-    }, flops_per_path, ctr.as_dict()
+    }, culled_flops_per_path, flops_per_path, {"reference": ctr.as_dict(), "with_candidate_sets": culled.as_dict()}
 
 
 def main():
@@ -75,6 +83,8 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
+    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "auto"],
+                    help="shadow-ray candidate sets (auto = tight with fast math, safe with strict)")
     ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4)")
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
@@ -108,7 +118,9 @@ def main():
     g = pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
                kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
                math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT, streams=args.streams,
-               passes_per_launch=args.passes_per_launch)
+               passes_per_launch=args.passes_per_launch,
+               shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "auto": pt.CULL_AUTO}[args.cull])
+    cull = args.cull if args.cull != "auto" else ("tight" if args.math == "fast" else "safe")
     g.set_scene(sc)
     g.resize(w, h, seeds)
     colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * w * h),
@@ -144,9 +156,10 @@ def main():
 
     if rank == 0:
         pixels = g.pixels()
-        baseline, flops_per_path, counters = (None, None, None)
+        baseline, flops_per_path, ref_flops_per_path, counters = (None, None, None, None)
         if world == 1 and not args.no_cpu:
-            baseline, flops_per_path, counters = cpu_baseline(args.scene)
+            baseline, flops_per_path, ref_flops_per_path, counters = cpu_baseline(
+                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT}[cull])
         # One step = args.passes passes.  With S region streams a pass is S concurrent launches of
         # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the
         # library's stream (fork/join), so the per-launch figure below is step time / sequential
@@ -160,7 +173,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            if (args.scene, w, h, args.kernel, args.math) == ("cornell", 1024, 768, "wavefront", "fast"):
+            if (args.scene, w, h, args.kernel, args.math, cull) == ("cornell", 1024, 768, "wavefront", "fast", tj.get("cull", "off")):
                 traffic = tj["bytes_per_pass"] * args.passes
         except (OSError, ValueError, KeyError):
             pass
@@ -177,6 +190,9 @@ def main():
                         "concurrent_launches_per_group": args.streams if ppl == 1 or args.streams > 1 else 1,
                         "passes_per_launch": ppl,
                         "algorithmic_flops_per_path": flops_per_path,
+                        "algorithm": f"reference integrator with shadow-ray candidate sets ({cull})",
+                        "reference_equivalent_flops_per_path": ref_flops_per_path,
+                        "reference_equivalent_tflops": ref_flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12,
                         "paths_per_step": paths_per_launch,
                         "hbm_algorithmic_bytes_per_pass": 44 * w * h}
         line = {
@@ -185,7 +201,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "scene file data/scenes/%s.txt (the reference's own), rand()-compatible seeds" % args.scene,
             "config": {"workload": f"{args.scene}.txt {w}x{h}, {args.passes} passes/step, "
-                                   f"{args.integrator} integrator, {args.kernel} kernel, {args.math} math",
+                                   f"{args.integrator} integrator, {args.kernel} kernel, {args.math} math, shadow cull {cull}",
                        "spp_timed": args.steps * args.passes, "spp_per_s": args.steps * args.passes * world / elapsed,
                        "parallelism": f"passes split over {world} GPU(s) by seed block + 1 all-reduce"},
             "roofline": roofline, "cpu_baseline": baseline,

@@ -45,7 +45,9 @@ enum {
                               one region's launch tail overlaps the other regions' work.  All
                               work is still ordered on the context's stream (fork/join events) */
     PTGPU_OPT_PASSES_PER_LAUNCH = 4, /* passes looped inside one kernel launch; 0 = automatic */
-    PTGPU_OPT_WAVES_PER_GROUP = 5    /* wavefront kernel: waves per workgroup, 1..16; 0 = default */
+    PTGPU_OPT_WAVES_PER_GROUP = 5,   /* wavefront kernel: waves per workgroup, 1..16; 0 = default */
+    PTGPU_OPT_SHADOW_CULL = 6        /* PTGPU_CULL_* (default AUTO): which primitives a shadow ray
+                                        towards a one-sided triangle light is tested against     */
 };
 enum {
     PTGPU_KERNEL_MEGA      = 0, /* one thread = one pixel = one whole path; the direct counterpart of
@@ -55,6 +57,22 @@ enum {
     PTGPU_KERNEL_AUTO      = 2  /* WAVEFRONT when the scene has two or more lights (the shadow-ray
                                    queue is what it is for), MEGA otherwise (measured 5-13 %
                                    faster on one-light scenes); same results either way          */
+};
+/* Shadow rays are only cast towards the FRONT of a triangle light (geomfunc.h:276-285 rejects a
+ * sample whose direction has a positive cosine with the light's normal), so a primitive that lies
+ * wholly behind the light's plane cannot be the occluder IntersectP (geomfunc.h:162-193) would
+ * find.  ptgpu_set_scene builds, per light, the set of primitives that are NOT wholly behind it;
+ * shadow rays scan that set instead of every object.  The answer of an any-hit scan does not depend
+ * on order, so the image is the brute-force one whenever no culled primitive could have been
+ * reported by the reference's floating-point tests:
+ *   SAFE  culls only primitives behind the plane by a margin (10 EPSILON + 1e-4 of their distance
+ *         to the light) far above any rounding of those tests: results stay bit-identical.
+ *   TIGHT also culls primitives that touch the plane from behind (closed half-space, tolerance
+ *         1e-5 relative): exact in real arithmetic; in floating point a ray grazing the light's
+ *         plane within rounding distance may see a different occluder than upstream.
+ *   AUTO  = SAFE under PTGPU_MATH_STRICT, TIGHT under PTGPU_MATH_FAST. */
+enum {
+    PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3
 };
 enum {
     PTGPU_MATH_FAST   = 0, /* FMA contraction on, v_rcp/v_rsq/v_sqrt/v_sin/v_cos f32 approximations:
@@ -138,8 +156,21 @@ typedef struct ptgpu_scene_info {
     uint32_t lights;       /* min(light_count, emissive primitives) */
     uint32_t segments;     /* runs of equal primitive type in index order */
     uint32_t lds_bytes;    /* LDS the staged records take per workgroup (0 = not staged) */
+    uint32_t shadow_groups;        /* groups of 4 primitives in the shadow-ray ordering (0 = no cull tables) */
+    float    shadow_tests_safe;    /* mean primitives tested per shadow ray under SAFE, light-averaged */
+    float    shadow_tests_tight;   /* same under TIGHT; equals `primitives` padded when nothing is culled */
 } ptgpu_scene_info;
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
+
+/* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
+ * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
+ * ptgpu_set_scene would stage from the same arguments and mode SAFE or TIGHT (OFF: all ones),
+ * keep[l * object_count + i] = 1 when object i is scanned for a shadow ray towards the l-th light
+ * (sampling order), 0 when it is culled or is not a sphere/triangle.  *n_lights receives the number
+ * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the
+ * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves. */
+int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count,
+                            int mode, uint8_t *keep, uint32_t *n_lights);
 
 const char *ptgpu_last_error(void);
 

@@ -67,6 +67,8 @@ def oracle():
                                                    C.POINTER(pt.Scene), C.c_int, C.c_int, _p, _p, _p,
                                                    C.c_int, C.c_int, C.c_int, C.POINTER(Counters)]
         lib.oracle_render_pass_counted.restype = None
+        lib.oracle_set_shadow_candidates.argtypes = [_p]
+        lib.oracle_set_shadow_candidates.restype = None
         _oracle = lib
     return _oracle
 
@@ -102,6 +104,22 @@ def ref():
                                          C.POINTER(C.c_uint)]
         _ref = lib
     return _ref
+
+
+class shadow_candidates:
+    """`with shadow_candidates(keep):` - oracle renders inside replay the product's shadow-ray culling
+    (keep = pyptgpu.shadow_candidates(scene, mode)); outside, the reference's full scan."""
+
+    def __init__(self, keep):
+        self.keep = np.ascontiguousarray(keep, dtype=np.uint8)
+
+    def __enter__(self):
+        oracle().oracle_set_shadow_candidates(_ptr(self.keep))
+        return self
+
+    def __exit__(self, *exc):
+        oracle().oracle_set_shadow_candidates(None)
+        return False
 
 
 class Render:

@@ -76,6 +76,11 @@ uint32_t oracle_accumulate(pt_vec3 *color, const pt_vec3 *sample, int current_sa
            (pack_channel(color->z, gamma) << 16);
 }
 
+/* Optional replay of the product's shadow-ray culling (NULL = the reference's full scan):
+ * keep[l * n_objects + i], l = light in sampling order.  Set between renders, read-only during. */
+static const uint8_t *g_shadow_keep = NULL;
+void oracle_set_shadow_candidates(const uint8_t *keep) { g_shadow_keep = keep; }
+
 /* ---- instance 1: plain ---- */
 #define FN(name) plain_##name
 #define TALLY(field) ((void)0)
@@ -125,7 +130,7 @@ int oracle_intersect(const pt_object *objects, uint32_t n, const pt_ray *ray, fl
 }
 
 int oracle_intersect_p(const pt_object *objects, uint32_t n, const pt_ray *ray, float maxt) {
-    return plain_any_hit(objects, n, ray, maxt);
+    return plain_any_hit(objects, n, ray, maxt, NULL);
 }
 
 void oracle_sample_lights(const pt_object *objects, uint32_t n, uint32_t lights, uint32_t *seed0,

@@ -78,12 +78,15 @@ static int FN(closest_hit)(const pt_object *objects, uint32_t n, const pt_ray *r
     return (*t < inf);
 }
 
-/* geomfunc.h:162-193: any hit closer than maxt, early out in index order */
+/* geomfunc.h:162-193: any hit closer than maxt, early out in index order.
+ * `candidates` (NULL upstream) replays the product's shadow-ray culling on the CPU: objects whose
+ * byte is 0 are skipped (oracle_set_shadow_candidates). */
 static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
-                       float maxt CTR_PARAM) {
+                       float maxt, const uint8_t *candidates CTR_PARAM) {
     TALLY(shadow_rays);
     for (uint32_t i = 0; i < n; i++) {
         float dist;
+        if (candidates && !candidates[i]) continue;
         if (objects[i].type == PT_SPHERE)
             dist = FN(hit_sphere)(&objects[i], ray CTR_ARG);
         else if (objects[i].type == PT_TRIANGLE)
@@ -154,11 +157,15 @@ static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t ligh
 
         float wo = v3_dot(shadow.d, light_normal);
         if (wo > 0.f) continue; /* back side of the light */
+        /* culled replay only for samples that provably face the light (a NaN normal passes the
+         * test above from either side) */
+        const uint8_t *candidates =
+            (g_shadow_keep && wo <= 0.f) ? g_shadow_keep + (size_t)(seen - 1) * n : NULL;
         wo = -wo;
         wo = clamp_macro(wo, 0.f, 1.f);
 
         const float wi = v3_dot(shadow.d, *normal);
-        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON CTR_ARG))) {
+        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates CTR_ARG))) {
             const float s = light->area * wi * wo / (len * len);
             const v3 contribution = v3_scale(s, light->emission);
             *result = v3_add(*result, contribution);

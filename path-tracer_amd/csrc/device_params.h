@@ -15,6 +15,15 @@
 //                          s1 = (color.xyz, sigma)  s2 = (kd.xyz, A)  s3 = (B, 0, 0, 0)
 //   lights [4 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
 //                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0)  l2 = (e2)  l3 = (emission.xyz, area)
+//
+// Shadow-ray tables (optional, see PTGPU_OPT_SHADOW_CULL in ptgpu.h):
+//   sprims [12 * (sg_sph + sg_tri)]  the same primitive records in shadow order: all spheres, padded
+//                          to a multiple of 4 with never-hit records, then all triangles, padded
+//                          likewise.  Group g = records of primitives 4g..4g+3, one type per group.
+//                          (An any-hit scan does not depend on the visiting order.)
+//   smask  [n_lights * (mw_sph + mw_tri)]  per light, 64-bit words: bit g of the first mw_sph words
+//                          = sphere group g may occlude a shadow ray towards this light; the next
+//                          mw_tri words the same for triangle groups.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,11 +48,16 @@ struct PtDeviceParams {
     // this launch covers tiles tile_first + k * tile_stride, k in [0, n_launch_tiles): the image is
     // dealt round-robin into regions so independent regions can run on concurrent streams
     int tile_first, tile_stride, n_launch_tiles;
+    // shadow-ray tables; smask == nullptr switches the culled scan off
+    const float4 *sprims;
+    const unsigned long long *smask;
+    int sg_sph, sg_tri;   // groups of 4 spheres / 4 triangles in sprims
+    int mw_sph, mw_tri;   // mask words per light for each
 };
 
 struct PtLaunchConfig {
     int use_lds;          // stage prims+lights in LDS
-    unsigned lds_bytes;   // dynamic LDS for the staged records
+    unsigned lds_bytes;   // dynamic LDS for the staged records (prims + lights [+ sprims])
     int waves_per_group;  // wavefront kernel: waves per workgroup (0 = default)
 };
 

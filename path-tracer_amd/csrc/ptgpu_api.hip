@@ -8,6 +8,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -55,6 +56,7 @@ struct ptgpu_ctx {
     int n_streams = kMaxStreams;      // regions rendered concurrently (PTGPU_OPT_STREAMS)
     int passes_per_launch = 0;        // 0 = automatic (PTGPU_OPT_PASSES_PER_LAUNCH)
     int waves_per_group = 0;          // 0 = default (PTGPU_OPT_WAVES_PER_GROUP)
+    int shadow_cull = PTGPU_CULL_AUTO; // PTGPU_OPT_SHADOW_CULL
     hipStream_t stream = nullptr;     // the context's stream: everything is ordered on it
     hipStream_t side[kMaxStreams - 1] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxStreams - 1] = {};
@@ -63,6 +65,11 @@ struct ptgpu_ctx {
     // scene
     float4 *d_prims = nullptr, *d_shade = nullptr, *d_lights = nullptr;
     int4 *d_segs = nullptr;
+    // shadow-ray tables (device_params.h); null when the scene gains nothing from them
+    float4 *d_sprims = nullptr;
+    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr;
+    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
+    uint32_t lds_bytes_with_shadow = 0;
     bool have_scene = false, have_camera = false;
     ptgpu_scene_info info{};
     pt_scene scene{};
@@ -87,6 +94,11 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_shade) (void)hipFree(c->d_shade);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_segs) (void)hipFree(c->d_segs);
+    if (c->d_sprims) (void)hipFree(c->d_sprims);
+    if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
+    if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
+    c->d_sprims = nullptr;
+    c->d_smask_safe = c->d_smask_tight = nullptr;
     c->d_prims = c->d_shade = c->d_lights = nullptr;
     c->d_segs = nullptr;
     c->have_scene = false;
@@ -141,7 +153,145 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.tile_first = 0;
     p.tile_stride = 1;
     p.n_launch_tiles = p.n_tiles;
+    int cull = c->shadow_cull;
+    if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_TIGHT;
+    p.sprims = c->d_sprims;
+    p.smask = cull == PTGPU_CULL_SAFE ? c->d_smask_safe : cull == PTGPU_CULL_TIGHT ? c->d_smask_tight : nullptr;
+    p.sg_sph = c->sg_sph;
+    p.sg_tri = c->sg_tri;
+    p.mw_sph = c->mw_sph;
+    p.mw_tri = c->mw_tri;
     return p;
+}
+
+// ---- shadow-ray candidate sets (PTGPU_OPT_SHADOW_CULL, ptgpu.h) ---------------------------------
+struct ShadowTables {
+    std::vector<float4> sprims;
+    std::vector<unsigned long long> safe, tight;
+    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
+    double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
+};
+
+struct D3 { double x, y, z; };
+D3 d3(const float4 &v) { return {v.x, v.y, v.z}; }
+D3 sub(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+D3 add(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+double len(D3 a) { return std::sqrt(dot(a, a)); }
+
+// keep[l * n_prims + i] = primitive i may occlude a shadow ray towards light l under `mode`
+// (PTGPU_CULL_SAFE / PTGPU_CULL_TIGHT; anything else keeps everything).
+// prims: 3 quads per primitive in index order; types[i]: PT_SPHERE / PT_TRIANGLE; lights: 4 quads each.
+std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const std::vector<int> &types,
+                                       const std::vector<float4> &lights, int mode) {
+    const size_t n_prims = types.size(), n_lights = lights.size() / 4;
+    std::vector<uint8_t> keep(n_lights * n_prims, 1);
+    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT) return keep;
+    const double eps = (double)PT_EPSILON;
+    for (size_t l = 0; l < n_lights; ++l) {
+        int light_type;
+        memcpy(&light_type, &lights[4 * l].w, sizeof light_type);
+        const D3 p0 = d3(lights[4 * l]), e1 = d3(lights[4 * l + 1]), e2 = d3(lights[4 * l + 2]);
+        D3 n = cross(e1, e2);
+        const double nn = len(n), size = len(e1) + len(e2);
+        // one-sided triangle lights with a usable normal; every other light keeps every primitive
+        if (light_type != PT_TRIANGLE || !std::isfinite(nn) || !(nn > 1e-12 * size * size)) continue;
+        n = {n.x / nn, n.y / nn, n.z / nn};
+        // `h` = height of a point of the primitive above the light's plane, `reach` = its distance
+        // from the light.  A NaN makes the comparison false: kept.
+        auto behind = [&](double h, double reach) {
+            return mode == PTGPU_CULL_SAFE ? h < -(10 * eps + 1e-4 * reach) : h <= 1e-5 * (reach + size);
+        };
+        for (size_t i = 0; i < n_prims; ++i) {
+            bool all_behind;
+            if (types[i] == PT_SPHERE) {
+                const D3 c = sub(d3(prims[3 * i]), p0);
+                const double r = std::fabs((double)prims[3 * i].w);
+                all_behind = behind(dot(c, n) + r, len(c) + r);
+            } else {
+                const D3 a = sub(d3(prims[3 * i]), p0);
+                const D3 b = add(a, d3(prims[3 * i + 1])), c = add(a, d3(prims[3 * i + 2]));
+                all_behind = behind(dot(a, n), len(a)) && behind(dot(b, n), len(b)) && behind(dot(c, n), len(c));
+            }
+            if (all_behind) keep[l * n_prims + i] = 0;
+        }
+    }
+    return keep;
+}
+
+void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int> &types,
+                         const std::vector<float4> &lights, ShadowTables &t) {
+    std::vector<int> sph, tri;
+    for (size_t i = 0; i < types.size(); ++i) (types[i] == PT_SPHERE ? sph : tri).push_back((int)i);
+    t.sg_sph = (int)((sph.size() + 3) / 4);
+    t.sg_tri = (int)((tri.size() + 3) / 4);
+    t.mw_sph = (t.sg_sph + 63) / 64;
+    t.mw_tri = (t.sg_tri + 63) / 64;
+    const float ninf = -__builtin_inff();
+    // never-hit fillers: a sphere with radius^2 = -inf (NaN discriminant fails every compare) and a
+    // triangle with zero edges (0 * inf = NaN barycentrics and distance, "t > EPSILON" fails)
+    auto put = [&](const std::vector<int> &ids, int groups, bool sphere) {
+        for (int k = 0; k < 4 * groups; ++k) {
+            if (k < (int)ids.size()) {
+                for (int q = 0; q < 3; ++q) t.sprims.push_back(prims[3 * ids[k] + q]);
+            } else {
+                t.sprims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+                t.sprims.push_back(sphere ? make_float4(ninf, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+                t.sprims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+        }
+    };
+    put(sph, t.sg_sph, true);
+    put(tri, t.sg_tri, false);
+
+    const size_t n_lights = lights.size() / 4, n_prims = types.size();
+    const int words = t.mw_sph + t.mw_tri;
+    auto masks = [&](int mode, std::vector<unsigned long long> &out, double &mean) {
+        const std::vector<uint8_t> keep = shadow_candidates(prims, types, lights, mode);
+        out.assign(n_lights * words, 0ull);
+        double total = 0;
+        for (size_t l = 0; l < n_lights; ++l) {
+            for (size_t k = 0; k < sph.size(); ++k)
+                if (keep[l * n_prims + sph[k]]) out[l * words + (k / 4) / 64] |= 1ull << ((k / 4) % 64);
+            for (size_t k = 0; k < tri.size(); ++k)
+                if (keep[l * n_prims + tri[k]]) out[l * words + t.mw_sph + (k / 4) / 64] |= 1ull << ((k / 4) % 64);
+            for (int w = 0; w < words; ++w) total += 4 * __builtin_popcountll(out[l * words + w]);
+        }
+        mean = n_lights ? total / n_lights : 0;
+    };
+    masks(PTGPU_CULL_SAFE, t.safe, t.mean_safe);
+    masks(PTGPU_CULL_TIGHT, t.tight, t.mean_tight);
+}
+
+// The device-side records of ptgpu_set_scene (device_params.h); shared with ptgpu_shadow_candidates.
+struct PackedScene {
+    std::vector<float4> prims, lights;
+    std::vector<int> types, object_of_prim;
+};
+void pack_geometry(const pt_object *objects, uint32_t object_count, uint32_t light_count, PackedScene &g) {
+    for (uint32_t i = 0; i < object_count; ++i) {
+        const pt_object &o = objects[i];
+        if (o.type != PT_SPHERE && o.type != PT_TRIANGLE) continue; // MODEL placeholders and junk are skipped
+        g.types.push_back((int)o.type);
+        g.object_of_prim.push_back((int)i);
+        if (o.type == PT_SPHERE) {
+            g.prims.push_back(make_float4(o.center.x, o.center.y, o.center.z, o.radius));
+            g.prims.push_back(make_float4(o.radius * o.radius, 0.f, 0.f, 0.f));
+            g.prims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        } else {
+            g.prims.push_back(make_float4(o.p1.x, o.p1.y, o.p1.z, 0.f));
+            g.prims.push_back(make_float4(o.p2.x - o.p1.x, o.p2.y - o.p1.y, o.p2.z - o.p1.z, 0.f));
+            g.prims.push_back(make_float4(o.p3.x - o.p1.x, o.p3.y - o.p1.y, o.p3.z - o.p1.z, 0.f));
+        }
+        if (emits(o.emission) && g.lights.size() / 4 < light_count) { // geomfunc.h:220: stop after lightCount emitters
+            const size_t q = g.prims.size() - 3;
+            g.lights.push_back(make_float4(g.prims[q].x, g.prims[q].y, g.prims[q].z, as_float((int)o.type)));
+            g.lights.push_back(o.type == PT_SPHERE ? make_float4(o.radius, 0.f, 0.f, 0.f) : g.prims[q + 1]);
+            g.lights.push_back(g.prims[q + 2]);
+            g.lights.push_back(make_float4(o.emission.x, o.emission.y, o.emission.z, o.area));
+        }
+    }
 }
 
 int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
@@ -151,10 +301,11 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     if (first_sample < 0 || n_passes < 0) return fail(PTGPU_ERR_ARGUMENT, "negative sample index or pass count");
     if (n_passes == 0) return PTGPU_OK;
     PtLaunchConfig cfg{};
-    cfg.use_lds = c->want_lds && c->info.lds_bytes > 0;
-    cfg.lds_bytes = cfg.use_lds ? c->info.lds_bytes : 0;
-    cfg.waves_per_group = c->waves_per_group;
     PtDeviceParams probe = make_params(c, first_sample, 1);
+    const uint32_t stage_bytes = probe.smask ? c->lds_bytes_with_shadow : c->info.lds_bytes;
+    cfg.use_lds = c->want_lds && stage_bytes > 0;
+    cfg.lds_bytes = cfg.use_lds ? stage_bytes : 0;
+    cfg.waves_per_group = c->waves_per_group;
     // One region per stream when the image has enough tiles to keep every region's launch wide.
     // Cheap scenes (a pass is tens of microseconds) gain nothing from overlapping tails and lose to
     // the extra launches, so they stay on one stream with the passes looped inside the launch.
@@ -296,6 +447,11 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         if (value < 0 || value > 16) return fail(PTGPU_ERR_ARGUMENT, "waves per group must be 0..16");
         ctx->waves_per_group = value;
         return PTGPU_OK;
+    case PTGPU_OPT_SHADOW_CULL:
+        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_AUTO)
+            return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
+        ctx->shadow_cull = value;
+        return PTGPU_OK;
     case PTGPU_OPT_PASSES_PER_LAUNCH:
         if (value < 0 || value > 64) return fail(PTGPU_ERR_ARGUMENT, "passes per launch must be 0..64");
         ctx->passes_per_launch = value;
@@ -314,30 +470,24 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         return fail(PTGPU_ERR_ARGUMENT, "ptgpu_set_scene: null argument");
     if (object_count > (1u << 24)) return fail(PTGPU_ERR_ARGUMENT, "too many objects (%u)", object_count);
 
-    std::vector<float4> prims, shade, lights;
+    PackedScene geo;
+    pack_geometry(objects, object_count, light_count, geo);
+    const std::vector<float4> &prims = geo.prims, &lights = geo.lights;
+    const std::vector<int> &types = geo.types;
+    std::vector<float4> shade;
     std::vector<int4> segs;
     ptgpu_scene_info info{};
-    for (uint32_t i = 0; i < object_count; ++i) {
-        const pt_object &o = objects[i];
-        if (o.type != PT_SPHERE && o.type != PT_TRIANGLE) continue; // MODEL placeholders and junk are skipped
+    info.primitives = (uint32_t)types.size();
+    info.lights = (uint32_t)(lights.size() / 4);
+    for (int p = 0; p < (int)types.size(); ++p) {
+        const pt_object &o = objects[geo.object_of_prim[p]];
         const bool light = emits(o.emission);
         if (!light && (o.material_id < 0 || (uint32_t)o.material_id >= material_count))
             return fail(PTGPU_ERR_ARGUMENT,
-                        "object %u uses material %d but only %u materials were given "
+                        "object %d uses material %d but only %u materials were given "
                         "(the reference would read past its material buffer)",
-                        i, (int)o.material_id, material_count);
-        const int p = (int)info.primitives++;
-        if (o.type == PT_SPHERE) {
-            info.spheres++;
-            prims.push_back(make_float4(o.center.x, o.center.y, o.center.z, o.radius));
-            prims.push_back(make_float4(o.radius * o.radius, 0.f, 0.f, 0.f));
-            prims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
-        } else {
-            info.triangles++;
-            prims.push_back(make_float4(o.p1.x, o.p1.y, o.p1.z, 0.f));
-            prims.push_back(make_float4(o.p2.x - o.p1.x, o.p2.y - o.p1.y, o.p2.z - o.p1.z, 0.f));
-            prims.push_back(make_float4(o.p3.x - o.p1.x, o.p3.y - o.p1.y, o.p3.z - o.p1.z, 0.f));
-        }
+                        geo.object_of_prim[p], (int)o.material_id, material_count);
+        (o.type == PT_SPHERE ? info.spheres : info.triangles)++;
         if (segs.empty() || segs.back().x != (int)o.type)
             segs.push_back(make_int4((int)o.type, p, p + 1, 0));
         else
@@ -350,22 +500,24 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         shade.push_back(make_float4(o.color.x, o.color.y, o.color.z, m.sigma));
         shade.push_back(make_float4(m.kd.x, m.kd.y, m.kd.z, m.A));
         shade.push_back(make_float4(m.B, 0.f, 0.f, 0.f));
-
-        if (light && info.lights < light_count) { // geomfunc.h:220: stop after lightCount emitters
-            info.lights++;
-            const size_t q = prims.size() - 3;
-            lights.push_back(make_float4(prims[q].x, prims[q].y, prims[q].z, as_float((int)o.type)));
-            if (o.type == PT_SPHERE)
-                lights.push_back(make_float4(o.radius, 0.f, 0.f, 0.f));
-            else
-                lights.push_back(prims[q + 1]);
-            lights.push_back(prims[q + 2]);
-            lights.push_back(make_float4(o.emission.x, o.emission.y, o.emission.z, o.area));
-        }
     }
     info.segments = (uint32_t)segs.size();
     const size_t staged = (prims.size() + lights.size()) * sizeof(float4);
     info.lds_bytes = staged <= kMaxStagedLdsBytes ? (uint32_t)staged : 0;
+
+    // Shadow-ray candidate sets: kept only when they pay (TIGHT removes at least a tenth of the
+    // tests, light-averaged) and stay small.
+    ShadowTables st;
+    bool use_tables = false;
+    if (info.lights > 0 && info.primitives > 0) {
+        build_shadow_tables(prims, types, lights, st);
+        const size_t mask_bytes = st.tight.size() * sizeof(unsigned long long);
+        use_tables = st.mean_tight <= 0.9 * info.primitives && mask_bytes <= (8u << 20);
+    }
+    info.shadow_groups = use_tables ? (uint32_t)(st.sg_sph + st.sg_tri) : 0;
+    info.shadow_tests_safe = use_tables ? (float)st.mean_safe : (float)info.primitives;
+    info.shadow_tests_tight = use_tables ? (float)st.mean_tight : (float)info.primitives;
+    const size_t staged_shadow = staged + (use_tables ? st.sprims.size() * sizeof(float4) : 0);
 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -380,9 +532,39 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     HIP_TRY(upload(ctx->d_shade, shade));
     HIP_TRY(upload(ctx->d_lights, lights));
     HIP_TRY(upload(ctx->d_segs, segs));
+    ctx->sg_sph = ctx->sg_tri = ctx->mw_sph = ctx->mw_tri = 0;
+    if (use_tables) {
+        HIP_TRY(upload(ctx->d_sprims, st.sprims));
+        HIP_TRY(upload(ctx->d_smask_safe, st.safe));
+        HIP_TRY(upload(ctx->d_smask_tight, st.tight));
+        ctx->sg_sph = st.sg_sph;
+        ctx->sg_tri = st.sg_tri;
+        ctx->mw_sph = st.mw_sph;
+        ctx->mw_tri = st.mw_tri;
+    }
+    // with the tables in use the shadow-order copy is staged next to the records, if all of it fits
+    ctx->lds_bytes_with_shadow = staged_shadow <= kMaxStagedLdsBytes ? (uint32_t)staged_shadow : 0;
     ctx->info = info;
     ctx->scene = *scene;
     ctx->have_scene = true;
+    return PTGPU_OK;
+}
+
+int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count, int mode,
+                            uint8_t *keep, uint32_t *n_lights) {
+    if (!objects || !n_lights) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: null argument");
+    if (mode < PTGPU_CULL_OFF || mode > PTGPU_CULL_TIGHT)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE or TIGHT");
+    PackedScene geo;
+    pack_geometry(objects, object_count, light_count, geo);
+    *n_lights = (uint32_t)(geo.lights.size() / 4);
+    if (!keep) return PTGPU_OK;
+    const std::vector<uint8_t> by_prim = shadow_candidates(geo.prims, geo.types, geo.lights, mode);
+    const size_t n_prims = geo.types.size();
+    memset(keep, 0, (size_t)*n_lights * object_count);
+    for (size_t l = 0; l < *n_lights; ++l)
+        for (size_t i = 0; i < n_prims; ++i)
+            keep[l * object_count + geo.object_of_prim[i]] = by_prim[l * n_prims + i];
     return PTGPU_OK;
 }
 

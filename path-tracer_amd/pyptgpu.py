@@ -218,20 +218,24 @@ def obj_parse(data: bytes):
 # libptgpu.so (HIP).  No fallback: a missing library or a missing GPU raises.
 # ---------------------------------------------------------------------------------------------
 OPT_KERNEL, OPT_MATH, OPT_LDS, OPT_STREAMS, OPT_PASSES_PER_LAUNCH, OPT_WAVES_PER_GROUP = 0, 1, 2, 3, 4, 5
+OPT_SHADOW_CULL = 6
+CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO = 0, 1, 2, 3
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
 
 
 class SceneInfo(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("primitives", "spheres", "triangles", "lights", "segments", "lds_bytes")]
+    _fields_ = ([(n, C.c_uint32) for n in ("primitives", "spheres", "triangles", "lights", "segments",
+                                          "lds_bytes", "shadow_groups")]
+                + [("shadow_tests_safe", C.c_float), ("shadow_tests_tight", C.c_float)])
 
 
 GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_scene", "ptgpu_set_camera",
                "ptgpu_resize", "ptgpu_render_pass", "ptgpu_render", "ptgpu_render_timed", "ptgpu_finish",
                "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
                "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
-               "ptgpu_last_error"]
+               "ptgpu_shadow_candidates", "ptgpu_last_error"]
 
 
 class GpuError(RuntimeError):
@@ -267,15 +271,29 @@ def gpu():
         lib.ptgpu_stream.argtypes = [vp, C.POINTER(vp)]
         lib.ptgpu_scale_and_repack.argtypes = [vp, C.c_float]
         lib.ptgpu_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
+        lib.ptgpu_shadow_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.POINTER(C.c_uint32)]
         _gpu = lib
     return _gpu
+
+
+def shadow_candidates(sc, mode, light_count=None):
+    """keep[l, i]: object i is scanned for a shadow ray towards light l under cull `mode` (host only)."""
+    lights = sc.light_count if light_count is None else light_count
+    n = C.c_uint32()
+    lib = gpu()
+    if lib.ptgpu_shadow_candidates(_ptr(sc.objects), sc.object_count, lights, mode, None, C.byref(n)) != 0:
+        raise GpuError(lib.ptgpu_last_error().decode())
+    keep = np.zeros((n.value, sc.object_count), dtype=np.uint8)
+    if lib.ptgpu_shadow_candidates(_ptr(sc.objects), sc.object_count, lights, mode, _ptr(keep), C.byref(n)) != 0:
+        raise GpuError(lib.ptgpu_last_error().decode())
+    return keep
 
 
 class Gpu:
     """One ptgpu context driven the way main-gpu.c drives its OpenCL objects."""
 
     def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None, streams=None,
-                 passes_per_launch=None, waves_per_group=None):
+                 passes_per_launch=None, waves_per_group=None, shadow_cull=None):
         self.lib = gpu()
         self.ctx = C.c_void_p()
         self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
@@ -291,6 +309,8 @@ class Gpu:
             self.set_option(OPT_PASSES_PER_LAUNCH, passes_per_launch)
         if waves_per_group is not None:
             self.set_option(OPT_WAVES_PER_GROUP, waves_per_group)
+        if shadow_cull is not None:
+            self.set_option(OPT_SHADOW_CULL, shadow_cull)
         self.w = self.h = 0
         self.sample = 0
 
@@ -365,7 +385,7 @@ class Gpu:
     def scene_info(self):
         info = SceneInfo()
         self._ok(self.lib.ptgpu_get_scene_info(self.ctx, C.byref(info)))
-        return {n: int(getattr(info, n)) for n, _ in info._fields_}
+        return {n: (float if t is C.c_float else int)(getattr(info, n)) for n, t in info._fields_}
 
     def close(self):
         if self.ctx:

@@ -30,10 +30,10 @@ KERNELS = [pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT]
 KNAME = {pt.KERNEL_MEGA: "mega", pt.KERNEL_WAVEFRONT: "wavefront"}
 
 
-def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False):
+def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False, cull=None):
     sc = pt.LoadedScene(name, w, h)
     seeds = pt.seed_block(w, h) if seeds is None else seeds
-    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds)
+    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds, shadow_cull=cull)
     g.set_scene(sc)
     g.resize(w, h, seeds)
     if per_pass:
@@ -73,6 +73,53 @@ def test_strict_is_bit_exact_against_oracle(case, lds, kernel):
     assert (sd == cpu.seeds).all()
     assert same_bits(colors, cpu.colors)
     assert (pixels == cpu.pixels).all()
+
+
+# The strict tests above run with the default cull mode, which is SAFE under strict math; the
+# brute-force scan (OFF) and SAFE must be the same image, bit for bit, with and without LDS staging.
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("lds", [1, 0])
+@pytest.mark.parametrize("case", [("cornell", 96, 72, 4, 0), ("cornell", 64, 48, 3, 1), ("materials", 96, 64, 6, 0),
+                                  ("cornell-with-hole", 64, 48, 4, 0)])
+def test_shadow_cull_off_and_safe_are_the_same_image(case, lds, kernel):
+    name, w, h, spp, integ = case
+    sc = pt.LoadedScene(name, w, h)
+    cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, integ).pass_oracle(spp, threads=8)
+    for cull in (pt.CULL_OFF, pt.CULL_SAFE):
+        colors, pixels, sd = gpu_render(name, w, h, spp, integ, kernel, pt.MATH_STRICT, lds=lds, cull=cull)
+        assert (sd == cpu.seeds).all()
+        assert same_bits(colors, cpu.colors)
+        assert (pixels == cpu.pixels).all()
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_shadow_cull_tight_equals_its_cpu_replay_bitwise(kernel):
+    # TIGHT may differ from the brute-force image (rays grazing a light's own plane), but it is
+    # still a fixed algorithm: the strict build must reproduce the oracle replaying the same sets.
+    name, w, h, spp = "cornell", 96, 72, 4
+    sc = pt.LoadedScene(name, w, h)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_TIGHT)):
+        cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_TIGHT)
+    assert (sd == cpu.seeds).all()
+    assert same_bits(colors, cpu.colors)
+    assert (pixels == cpu.pixels).all()
+
+
+def test_shadow_cull_full_size_cornell_safe_is_brute_force():
+    # 1024x768 x 4 passes: ~8e8 shadow rays; SAFE and OFF must agree in every bit (NaN pixels included)
+    w, h, spp = 1024, 768, 4
+    off = gpu_render("cornell", w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_STRICT, cull=pt.CULL_OFF)
+    safe = gpu_render("cornell", w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_STRICT, cull=pt.CULL_SAFE)
+    assert same_bits(off[0], safe[0]) and (off[1] == safe[1]).all() and (off[2] == safe[2]).all()
+    tight = gpu_render("cornell", w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_STRICT, cull=pt.CULL_TIGHT)
+    assert (tight[2] == off[2]).all()                         # same draw sequence
+    ok = ~np.isnan(off[0]).any(1) & ~np.isnan(tight[0]).any(1)
+    moved = (np.abs(tight[0][ok] - off[0][ok]).max(1) > 1e-4).mean()
+    print(f"TIGHT vs brute force, strict, {w}x{h}x{spp}: {moved:.4%} of pixels moved by > 1e-4")
+    assert moved < 0.05                                       # the FP floor on cornell is ~50 %
+    mean_off, mean_tight = off[0][ok].mean(), tight[0][ok].mean()
+    assert abs(mean_tight - mean_off) <= 2e-3 * mean_off       # no energy drift
 
 
 # floor RMSE between the two CPU builds of the reference, SURVEY.md 8-c calibration table

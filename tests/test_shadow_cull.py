@@ -1,0 +1,114 @@
+"""Shadow-ray candidate sets (PTGPU_OPT_SHADOW_CULL): the host-side tables and, replayed by the CPU
+oracle, their effect on the image.  No GPU: ptgpu_shadow_candidates is host code in libptgpu.so.
+
+What is proven here on the CPU
+  * SAFE never changes a bit of the oracle's image (colours, pixels, RNG state) on the reference's
+    scenes, both integrators - the same bar as the brute-force scan;
+  * TIGHT is a subset of SAFE, culls only primitives that lie in the closed half-space behind the
+    light's plane, and moves the image by less than the calibrated FP floor (it can differ only for
+    rays that graze the light's own plane, where the contribution's cosine factor is ~0).
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pyptgpu as pt
+from conftest import same_bits
+
+SCENES = ["cornell", "materials", "cornell-with-hole", "obj-model", "simple", "cornell-large", "caustic",
+          "table-and-mirror", "stacked-spheres"]
+
+
+def geometry(sc):
+    o = sc.objects
+    real = (o["type"] == 0) | (o["type"] == 1)
+    emissive = ~((o["emission"][:, 0] == 0) & (o["emission"][:, 2] == 0)) & real   # vec.h:23 looks at x and z
+    lights = np.nonzero(emissive)[0][: sc.light_count]
+    return o, real, lights
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_tables_are_consistent(name):
+    sc = pt.LoadedScene(name, 32, 24)
+    o, real, lights = geometry(sc)
+    off = pt.shadow_candidates(sc, pt.CULL_OFF)
+    safe = pt.shadow_candidates(sc, pt.CULL_SAFE)
+    tight = pt.shadow_candidates(sc, pt.CULL_TIGHT)
+    assert off.shape == safe.shape == tight.shape == (len(lights), sc.object_count)
+    assert (off == real[None, :]).all()                      # OFF: every sphere/triangle, no MODEL placeholder
+    assert (safe <= off).all() and (tight <= safe).all()     # nested
+    for l, li in enumerate(lights):
+        if o["type"][li] == 0:                               # sphere lights are sampled from every side
+            assert (safe[l] == off[l]).all() and (tight[l] == off[l]).all()
+            continue
+        assert safe[l, li] == 1                              # a light is in front of nothing, itself included
+        p0 = o["p1"][li].astype(np.float64)
+        n = np.cross(o["p2"][li].astype(np.float64) - p0, o["p3"][li].astype(np.float64) - p0)
+        n /= np.linalg.norm(n)
+        for i in np.nonzero(real & (tight[l] == 0))[0]:      # whatever TIGHT culls lies behind the plane
+            if o["type"][i] == 1:
+                top = max(float((o[k][i].astype(np.float64) - p0) @ n) for k in ("p1", "p2", "p3"))
+                scale = max(np.linalg.norm(o[k][i].astype(np.float64) - p0) for k in ("p1", "p2", "p3"))
+            else:
+                top = float((o["center"][i].astype(np.float64) - p0) @ n) + abs(float(o["radius"][i]))
+                scale = np.linalg.norm(o["center"][i].astype(np.float64) - p0) + abs(float(o["radius"][i]))
+            assert top <= 1e-4 * (scale + 1.0), (name, l, i, top)
+        for i in np.nonzero(real & (safe[l] == 0))[0]:       # SAFE: behind by at least 10 EPSILON
+            if o["type"][i] == 1:
+                top = max(float((o[k][i].astype(np.float64) - p0) @ n) for k in ("p1", "p2", "p3"))
+            else:
+                top = float((o["center"][i].astype(np.float64) - p0) @ n) + abs(float(o["radius"][i]))
+            assert top < -0.1
+
+
+def test_light_count_limits_rows_and_bad_arguments():
+    sc = pt.LoadedScene("cornell", 32, 24)
+    assert pt.shadow_candidates(sc, pt.CULL_SAFE, light_count=5).shape == (5, sc.object_count)
+    assert pt.shadow_candidates(sc, pt.CULL_SAFE, light_count=0).shape == (0, sc.object_count)
+    with pytest.raises(pt.GpuError):
+        pt.shadow_candidates(sc, 7)
+
+
+@pytest.mark.parametrize("integrator", [0, 1], ids=["pt", "dl"])
+@pytest.mark.parametrize("case", [("cornell", 64, 48, 3), ("materials", 96, 64, 4), ("cornell-with-hole", 48, 36, 3),
+                                  ("obj-model", 40, 30, 2), ("table-and-mirror", 48, 36, 3)])
+def test_safe_replay_is_bit_identical_on_the_cpu(case, integrator):
+    name, w, h, spp = case
+    sc = pt.LoadedScene(name, w, h)
+    seeds = pt.seed_block(w, h)
+    full = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, integrator).pass_oracle(spp, threads=8)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_SAFE)):
+        culled = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, integrator).pass_oracle(spp, threads=8)
+    assert same_bits(culled.colors, full.colors)
+    assert (culled.pixels == full.pixels).all() and (culled.seeds == full.seeds).all()
+
+
+def test_tight_replay_moves_cornell_less_than_the_fp_floor():
+    # two CPU builds of the reference that differ only in FP evaluation disagree on
+    # cornell 48x36x8 with RMSE 1.1e-2 and on 51.7 % of the pixels; TIGHT must stay inside that.
+    w, h, spp = 48, 36, 8
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    full = ob.Render(sc, seeds).pass_oracle(spp, threads=8)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_TIGHT)):
+        culled = ob.Render(sc, seeds).pass_oracle(spp, threads=8)
+    assert (culled.seeds == full.seeds).all()                 # visibility never changes the draw sequence
+    ok = ~np.isnan(full.colors).any(1) & ~np.isnan(culled.colors).any(1)
+    assert (np.isnan(full.colors).any(1) == np.isnan(culled.colors).any(1)).all()
+    d = (culled.colors[ok].astype(np.float64) - full.colors[ok])
+    rmse = np.sqrt((d ** 2).mean())
+    print('TIGHT replay: rmse', rmse, 'share moved', (np.abs(d).max(1) > 1e-4).mean())
+    assert rmse <= 1.1e-2
+    assert (np.abs(d).max(1) > 1e-4).mean() <= 0.1 * 0.517
+
+
+def test_counting_replay_reports_fewer_tests_and_same_draws():
+    sc = pt.LoadedScene("cornell", 32, 24)
+    seeds = pt.seed_block(32, 24)
+    a, b = ob.Counters(), ob.Counters()
+    ob.Render(sc, seeds).pass_oracle_counted(a, 1)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_SAFE)):
+        ob.Render(sc, seeds).pass_oracle_counted(b, 1)
+    assert (a.rng_draws, a.light_samples, a.extension_rays, a.shadow_rays) == \
+           (b.rng_draws, b.light_samples, b.extension_rays, b.shadow_rays)
+    assert b.triangle_tests < 0.8 * a.triangle_tests

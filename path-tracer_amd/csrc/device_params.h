@@ -13,13 +13,18 @@
 //     (geomfunc.h:149); the run structure makes the inner loops type-pure.
 //   shade  [4 * n_prims]   s0 = (emission.xyz, flags)  flags = material type | emissive << 8 | prim type << 16
 //                          s1 = (color.xyz, sigma)  s2 = (kd.xyz, A)  s3 = (B, 0, 0, 0)
-//   lights [4 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
+//   lights [5 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
 //                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0)  l2 = (e2)  l3 = (emission.xyz, area)
+//                          l4 = (unit normal of e1 x e2, plane offset n.p1 lowered by a tolerance) for
+//                               triangle lights; (0,0,0,-1) for spheres and degenerate triangles.
+//                               A point x with n.x < l4.w is behind the light: every sample of the
+//                               light is rejected there (geomfunc.h:276-285).  Read by the fast build only.
 //
 // Shadow-ray tables (optional, see PTGPU_OPT_SHADOW_CULL in ptgpu.h):
-//   sprims [12 * (sg_sph + sg_tri)]  the same primitive records in shadow order: all spheres, padded
-//                          to a multiple of 4 with never-hit records, then all triangles, padded
-//                          likewise.  Group g = records of primitives 4g..4g+3, one type per group.
+//   sprims [3 * (2 sg_sph + 4 sg_tri)]  the same primitive records in shadow order: all spheres,
+//                          padded to a multiple of kSphereGroup with never-hit records, then all
+//                          triangles, padded to a multiple of kTriGroup.  A group = that many
+//                          consecutive primitives of one type, tested back to back.
 //                          (An any-hit scan does not depend on the visiting order.)
 //   smask  [n_lights * (mw_sph + mw_tri)]  per light, 64-bit words: bit g of the first mw_sph words
 //                          = sphere group g may occlude a shadow ray towards this light; the next
@@ -27,6 +32,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+constexpr int kLightQuads = 5;
+constexpr int kSphereGroup = 2, kTriGroup = 4; // primitives per shadow group (a sphere test is ~17 VALU, a triangle ~37)
 
 struct PtDeviceParams {
     const float4 *prims;
@@ -51,7 +59,7 @@ struct PtDeviceParams {
     // shadow-ray tables; smask == nullptr switches the culled scan off
     const float4 *sprims;
     const unsigned long long *smask;
-    int sg_sph, sg_tri;   // groups of 4 spheres / 4 triangles in sprims
+    int sg_sph, sg_tri;   // sphere / triangle groups in sprims
     int mw_sph, mw_tri;   // mask words per light for each
 };
 

@@ -113,6 +113,12 @@ void free_image(ptgpu_ctx *c) {
     c->width = c->height = 0;
 }
 
+int as_int(float f) {
+    int v;
+    memcpy(&v, &f, sizeof v);
+    return v;
+}
+
 float as_float(int v) {
     float f;
     memcpy(&f, &v, sizeof f);
@@ -224,15 +230,15 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
                          const std::vector<float4> &lights, ShadowTables &t) {
     std::vector<int> sph, tri;
     for (size_t i = 0; i < types.size(); ++i) (types[i] == PT_SPHERE ? sph : tri).push_back((int)i);
-    t.sg_sph = (int)((sph.size() + 3) / 4);
-    t.sg_tri = (int)((tri.size() + 3) / 4);
+    t.sg_sph = (int)((sph.size() + kSphereGroup - 1) / kSphereGroup);
+    t.sg_tri = (int)((tri.size() + kTriGroup - 1) / kTriGroup);
     t.mw_sph = (t.sg_sph + 63) / 64;
     t.mw_tri = (t.sg_tri + 63) / 64;
     const float ninf = -__builtin_inff();
     // never-hit fillers: a sphere with radius^2 = -inf (NaN discriminant fails every compare) and a
     // triangle with zero edges (0 * inf = NaN barycentrics and distance, "t > EPSILON" fails)
     auto put = [&](const std::vector<int> &ids, int groups, bool sphere) {
-        for (int k = 0; k < 4 * groups; ++k) {
+        for (int k = 0; k < (sphere ? kSphereGroup : kTriGroup) * groups; ++k) {
             if (k < (int)ids.size()) {
                 for (int q = 0; q < 3; ++q) t.sprims.push_back(prims[3 * ids[k] + q]);
             } else {
@@ -253,10 +259,13 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
             for (size_t k = 0; k < sph.size(); ++k)
-                if (keep[l * n_prims + sph[k]]) out[l * words + (k / 4) / 64] |= 1ull << ((k / 4) % 64);
+                if (keep[l * n_prims + sph[k]])
+                    out[l * words + (k / kSphereGroup) / 64] |= 1ull << ((k / kSphereGroup) % 64);
             for (size_t k = 0; k < tri.size(); ++k)
-                if (keep[l * n_prims + tri[k]]) out[l * words + t.mw_sph + (k / 4) / 64] |= 1ull << ((k / 4) % 64);
-            for (int w = 0; w < words; ++w) total += 4 * __builtin_popcountll(out[l * words + w]);
+                if (keep[l * n_prims + tri[k]])
+                    out[l * words + t.mw_sph + (k / kTriGroup) / 64] |= 1ull << ((k / kTriGroup) % 64);
+            for (int w = 0; w < words; ++w)
+                total += (w < t.mw_sph ? kSphereGroup : kTriGroup) * __builtin_popcountll(out[l * words + w]);
         }
         mean = n_lights ? total / n_lights : 0;
     };
@@ -502,7 +511,24 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         shade.push_back(make_float4(m.B, 0.f, 0.f, 0.f));
     }
     info.segments = (uint32_t)segs.size();
-    const size_t staged = (prims.size() + lights.size()) * sizeof(float4);
+    // device light records: the four geometry/emission quads + the plane quad (device_params.h)
+    std::vector<float4> dlights;
+    for (size_t l = 0; l < lights.size() / 4; ++l) {
+        for (int q = 0; q < 4; ++q) dlights.push_back(lights[4 * l + q]);
+        float4 plane = make_float4(0.f, 0.f, 0.f, -1.f);
+        if (as_int(lights[4 * l].w) == PT_TRIANGLE) {
+            const D3 p1 = d3(lights[4 * l]), e1 = d3(lights[4 * l + 1]), e2 = d3(lights[4 * l + 2]);
+            const D3 n = cross(e1, e2);
+            const double nn = len(n), size = len(e1) + len(e2);
+            if (std::isfinite(nn) && nn > 1e-12 * size * size) {
+                const float nx = (float)(n.x / nn), ny = (float)(n.y / nn), nz = (float)(n.z / nn);
+                const double tol = 1e-4 * (len(p1) + size + 1.0);
+                plane = make_float4(nx, ny, nz, (float)(dot(p1, {nx, ny, nz}) - tol));
+            }
+        }
+        dlights.push_back(plane);
+    }
+    const size_t staged = (prims.size() + dlights.size()) * sizeof(float4);
     info.lds_bytes = staged <= kMaxStagedLdsBytes ? (uint32_t)staged : 0;
 
     // Shadow-ray candidate sets: kept only when they pay (TIGHT removes at least a tenth of the
@@ -530,7 +556,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     };
     HIP_TRY(upload(ctx->d_prims, prims));
     HIP_TRY(upload(ctx->d_shade, shade));
-    HIP_TRY(upload(ctx->d_lights, lights));
+    HIP_TRY(upload(ctx->d_lights, dlights));
     HIP_TRY(upload(ctx->d_segs, segs));
     ctx->sg_sph = ctx->sg_tri = ctx->mw_sph = ctx->mw_tri = 0;
     if (use_tables) {

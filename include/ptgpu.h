@@ -155,7 +155,7 @@ typedef struct ptgpu_scene_info {
     uint32_t triangles;
     uint32_t lights;       /* min(light_count, emissive primitives) */
     uint32_t segments;     /* runs of equal primitive type in index order */
-    uint32_t lds_bytes;    /* LDS the staged records take per workgroup (0 = not staged) */
+    uint32_t lds_bytes;    /* LDS the staged records take per workgroup in the fast build (0 = not staged) */
     uint32_t shadow_groups;        /* primitive groups in the shadow-ray ordering (0 = no cull tables) */
     float    shadow_tests_safe;    /* mean primitives tested per shadow ray under SAFE, light-averaged */
     float    shadow_tests_tight;   /* same under TIGHT; equals `primitives` padded when nothing is culled */

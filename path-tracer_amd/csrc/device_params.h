@@ -56,8 +56,10 @@ struct PtDeviceParams {
     // this launch covers tiles tile_first + k * tile_stride, k in [0, n_launch_tiles): the image is
     // dealt round-robin into regions so independent regions can run on concurrent streams
     int tile_first, tile_stride, n_launch_tiles;
-    // shadow-ray tables; smask == nullptr switches the culled scan off
+    // shadow order: always present (the fast build traces every ray in it); smask == nullptr
+    // switches the per-light candidate sets off
     const float4 *sprims;
+    const float4 *sshade;   // shade records in shadow order, zero for the fillers
     const unsigned long long *smask;
     int sg_sph, sg_tri;   // sphere / triangle groups in sprims
     int mw_sph, mw_tri;   // mask words per light for each
@@ -65,7 +67,7 @@ struct PtDeviceParams {
 
 struct PtLaunchConfig {
     int use_lds;          // stage prims+lights in LDS
-    unsigned lds_bytes;   // dynamic LDS for the staged records (prims + lights [+ sprims])
+    unsigned lds_bytes;   // dynamic LDS for the staged records (see stage_records)
     int waves_per_group;  // wavefront kernel: waves per workgroup (0 = default)
 };
 

@@ -66,10 +66,11 @@ struct ptgpu_ctx {
     float4 *d_prims = nullptr, *d_shade = nullptr, *d_lights = nullptr;
     int4 *d_segs = nullptr;
     // shadow-ray tables (device_params.h); null when the scene gains nothing from them
-    float4 *d_sprims = nullptr;
+    float4 *d_sprims = nullptr, *d_sshade = nullptr;
     unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
-    uint32_t lds_bytes_with_shadow = 0;
+    // LDS for the staged records per build and cull state (0 = does not fit, read from global)
+    uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
     bool have_scene = false, have_camera = false;
     ptgpu_scene_info info{};
     pt_scene scene{};
@@ -95,6 +96,8 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_segs) (void)hipFree(c->d_segs);
     if (c->d_sprims) (void)hipFree(c->d_sprims);
+    if (c->d_sshade) (void)hipFree(c->d_sshade);
+    c->d_sshade = nullptr;
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     c->d_sprims = nullptr;
@@ -162,6 +165,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     int cull = c->shadow_cull;
     if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_TIGHT;
     p.sprims = c->d_sprims;
+    p.sshade = c->d_sshade;
     p.smask = cull == PTGPU_CULL_SAFE ? c->d_smask_safe : cull == PTGPU_CULL_TIGHT ? c->d_smask_tight : nullptr;
     p.sg_sph = c->sg_sph;
     p.sg_tri = c->sg_tri;
@@ -173,6 +177,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
 // ---- shadow-ray candidate sets (PTGPU_OPT_SHADOW_CULL, ptgpu.h) ---------------------------------
 struct ShadowTables {
     std::vector<float4> sprims;
+    std::vector<int> prim_of_slot;   // shadow-order slot -> primitive index, -1 for a filler
     std::vector<unsigned long long> safe, tight;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
     double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
@@ -239,6 +244,7 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     // triangle with zero edges (0 * inf = NaN barycentrics and distance, "t > EPSILON" fails)
     auto put = [&](const std::vector<int> &ids, int groups, bool sphere) {
         for (int k = 0; k < (sphere ? kSphereGroup : kTriGroup) * groups; ++k) {
+            t.prim_of_slot.push_back(k < (int)ids.size() ? ids[k] : -1);
             if (k < (int)ids.size()) {
                 for (int q = 0; q < 3; ++q) t.sprims.push_back(prims[3 * ids[k] + q]);
             } else {
@@ -311,7 +317,7 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     if (n_passes == 0) return PTGPU_OK;
     PtLaunchConfig cfg{};
     PtDeviceParams probe = make_params(c, first_sample, 1);
-    const uint32_t stage_bytes = probe.smask ? c->lds_bytes_with_shadow : c->info.lds_bytes;
+    const uint32_t stage_bytes = c->math == PTGPU_MATH_FAST ? c->lds_fast : probe.smask ? c->lds_strict_cull : c->lds_strict;
     cfg.use_lds = c->want_lds && stage_bytes > 0;
     cfg.lds_bytes = cfg.use_lds ? stage_bytes : 0;
     cfg.waves_per_group = c->waves_per_group;
@@ -528,22 +534,26 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         }
         dlights.push_back(plane);
     }
-    const size_t staged = (prims.size() + dlights.size()) * sizeof(float4);
-    info.lds_bytes = staged <= kMaxStagedLdsBytes ? (uint32_t)staged : 0;
 
-    // Shadow-ray candidate sets: kept only when they pay (TIGHT removes at least a tenth of the
-    // tests, light-averaged) and stay small.
+    // Shadow order (always: the fast build traces in it) and the per-light candidate sets, which
+    // are kept only when they pay (TIGHT removes at least a tenth of the tests, light-averaged)
+    // and stay small.
     ShadowTables st;
-    bool use_tables = false;
-    if (info.lights > 0 && info.primitives > 0) {
-        build_shadow_tables(prims, types, lights, st);
-        const size_t mask_bytes = st.tight.size() * sizeof(unsigned long long);
-        use_tables = st.mean_tight <= 0.9 * info.primitives && mask_bytes <= (8u << 20);
-    }
-    info.shadow_groups = use_tables ? (uint32_t)(st.sg_sph + st.sg_tri) : 0;
+    build_shadow_tables(prims, types, lights, st);
+    std::vector<float4> sshade;
+    for (int slot : st.prim_of_slot)
+        for (int q = 0; q < 4; ++q) sshade.push_back(slot >= 0 ? shade[4 * slot + q] : make_float4(0.f, 0.f, 0.f, 0.f));
+    const size_t mask_bytes = st.tight.size() * sizeof(unsigned long long);
+    const bool use_tables = info.lights > 0 && st.mean_tight <= 0.9 * info.primitives && mask_bytes <= (8u << 20);
+    info.shadow_groups = (uint32_t)(st.sg_sph + st.sg_tri);
     info.shadow_tests_safe = use_tables ? (float)st.mean_safe : (float)info.primitives;
     info.shadow_tests_tight = use_tables ? (float)st.mean_tight : (float)info.primitives;
-    const size_t staged_shadow = staged + (use_tables ? st.sprims.size() * sizeof(float4) : 0);
+    auto fits = [](size_t bytes) { return bytes <= kMaxStagedLdsBytes ? (uint32_t)bytes : 0u; };
+    const size_t light_bytes = dlights.size() * sizeof(float4), shadow_bytes = st.sprims.size() * sizeof(float4);
+    const uint32_t lds_strict = fits(prims.size() * sizeof(float4) + light_bytes);
+    const uint32_t lds_strict_cull = fits(prims.size() * sizeof(float4) + light_bytes + shadow_bytes);
+    const uint32_t lds_fast = fits(shadow_bytes + light_bytes);
+    info.lds_bytes = lds_fast;
 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
@@ -558,18 +568,19 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     HIP_TRY(upload(ctx->d_shade, shade));
     HIP_TRY(upload(ctx->d_lights, dlights));
     HIP_TRY(upload(ctx->d_segs, segs));
-    ctx->sg_sph = ctx->sg_tri = ctx->mw_sph = ctx->mw_tri = 0;
+    HIP_TRY(upload(ctx->d_sprims, st.sprims));
+    HIP_TRY(upload(ctx->d_sshade, sshade));
     if (use_tables) {
-        HIP_TRY(upload(ctx->d_sprims, st.sprims));
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));
         HIP_TRY(upload(ctx->d_smask_tight, st.tight));
-        ctx->sg_sph = st.sg_sph;
-        ctx->sg_tri = st.sg_tri;
-        ctx->mw_sph = st.mw_sph;
-        ctx->mw_tri = st.mw_tri;
     }
-    // with the tables in use the shadow-order copy is staged next to the records, if all of it fits
-    ctx->lds_bytes_with_shadow = staged_shadow <= kMaxStagedLdsBytes ? (uint32_t)staged_shadow : 0;
+    ctx->sg_sph = st.sg_sph;
+    ctx->sg_tri = st.sg_tri;
+    ctx->mw_sph = st.mw_sph;
+    ctx->mw_tri = st.mw_tri;
+    ctx->lds_strict = lds_strict;
+    ctx->lds_strict_cull = lds_strict_cull;
+    ctx->lds_fast = lds_fast;
     ctx->info = info;
     ctx->scene = *scene;
     ctx->have_scene = true;

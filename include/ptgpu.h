@@ -46,8 +46,10 @@ enum {
                               work is still ordered on the context's stream (fork/join events) */
     PTGPU_OPT_PASSES_PER_LAUNCH = 4, /* passes looped inside one kernel launch; 0 = automatic */
     PTGPU_OPT_WAVES_PER_GROUP = 5,   /* wavefront kernel: waves per workgroup, 1..16; 0 = default */
-    PTGPU_OPT_SHADOW_CULL = 6        /* PTGPU_CULL_* (default AUTO): which primitives a shadow ray
+    PTGPU_OPT_SHADOW_CULL = 6,       /* PTGPU_CULL_* (default AUTO): which primitives a shadow ray
                                         towards a one-sided triangle light is tested against     */
+    PTGPU_OPT_RAY_BINS = 7           /* 1 (default) = fast build with TIGHT sets bins shadow rays on
+                                        triangle clusters (wavefront kernel); 0 = one queue        */
 };
 enum {
     PTGPU_KERNEL_MEGA      = 0, /* one thread = one pixel = one whole path; the direct counterpart of
@@ -159,6 +161,8 @@ typedef struct ptgpu_scene_info {
     uint32_t shadow_groups;        /* primitive groups in the shadow-ray ordering (0 = no cull tables) */
     float    shadow_tests_safe;    /* mean primitives tested per shadow ray under SAFE, light-averaged */
     float    shadow_tests_tight;   /* same under TIGHT; equals `primitives` padded when nothing is culled */
+    uint32_t clusters;             /* triangle clusters the fast build bins shadow rays on (0..8) */
+    uint32_t clustered_triangles;  /* triangles inside them */
 } ptgpu_scene_info;
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 

@@ -14,7 +14,8 @@
 //   shade  [4 * n_prims]   s0 = (emission.xyz, flags)  flags = material type | emissive << 8 | prim type << 16
 //                          s1 = (color.xyz, sigma)  s2 = (kd.xyz, A)  s3 = (B, 0, 0, 0)
 //   lights [5 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
-//                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0)  l2 = (e2)  l3 = (emission.xyz, area)
+//                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0; w = bit c set when cluster c has a
+//                          group in the light's TIGHT set)  l2 = (e2)  l3 = (emission.xyz, area)
 //                          l4 = (unit normal of e1 x e2, plane offset n.p1 lowered by a tolerance) for
 //                               triangle lights; (0,0,0,-1) for spheres and degenerate triangles.
 //                               A point x with n.x < l4.w is behind the light: every sample of the
@@ -26,6 +27,8 @@
 //                          triangles, padded to a multiple of kTriGroup.  A group = that many
 //                          consecutive primitives of one type, tested back to back.
 //                          (An any-hit scan does not depend on the visiting order.)
+//     Triangles are ordered cluster by cluster (connected components of the meshes, the 8 largest
+//     with >= 8 triangles), each cluster padded to whole groups, unclustered triangles last.
 //   smask  [n_lights * (mw_sph + mw_tri)]  per light, 64-bit words: bit g of the first mw_sph words
 //                          = sphere group g may occlude a shadow ray towards this light; the next
 //                          mw_tri words the same for triangle groups.
@@ -63,6 +66,11 @@ struct PtDeviceParams {
     const unsigned long long *smask;
     int sg_sph, sg_tri;   // sphere / triangle groups in sprims
     int mw_sph, mw_tri;   // mask words per light for each
+    // triangle clusters (fast build, TIGHT sets): n_clusters == 0 switches the ray binning off
+    const unsigned long long *cmask;  // (1 + n_clusters) x mw_tri words: row 0 = triangle groups in no
+                                      // cluster, row 1 + c = groups of cluster c
+    const float4 *cbounds;            // n_clusters x (centre, padded radius), staged after the lights
+    int n_clusters;
 };
 
 struct PtLaunchConfig {

@@ -8,7 +8,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cmath>
+#include <map>
 #include <cstring>
 #include <vector>
 
@@ -57,6 +59,7 @@ struct ptgpu_ctx {
     int passes_per_launch = 0;        // 0 = automatic (PTGPU_OPT_PASSES_PER_LAUNCH)
     int waves_per_group = 0;          // 0 = default (PTGPU_OPT_WAVES_PER_GROUP)
     int shadow_cull = PTGPU_CULL_AUTO; // PTGPU_OPT_SHADOW_CULL
+    int ray_bins = 1;                  // PTGPU_OPT_RAY_BINS
     hipStream_t stream = nullptr;     // the context's stream: everything is ordered on it
     hipStream_t side[kMaxStreams - 1] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxStreams - 1] = {};
@@ -67,8 +70,9 @@ struct ptgpu_ctx {
     int4 *d_segs = nullptr;
     // shadow-ray tables (device_params.h); null when the scene gains nothing from them
     float4 *d_sprims = nullptr, *d_sshade = nullptr;
-    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr;
-    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
+    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_cmask = nullptr;
+    float4 *d_cbounds = nullptr;
+    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
     uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
     bool have_scene = false, have_camera = false;
@@ -98,6 +102,10 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_sprims) (void)hipFree(c->d_sprims);
     if (c->d_sshade) (void)hipFree(c->d_sshade);
     c->d_sshade = nullptr;
+    if (c->d_cmask) (void)hipFree(c->d_cmask);
+    if (c->d_cbounds) (void)hipFree(c->d_cbounds);
+    c->d_cmask = nullptr;
+    c->d_cbounds = nullptr;
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     c->d_sprims = nullptr;
@@ -171,6 +179,11 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.sg_tri = c->sg_tri;
     p.mw_sph = c->mw_sph;
     p.mw_tri = c->mw_tri;
+    // ray binning on triangle clusters: fast build, TIGHT sets only (the bins are built from them)
+    const bool bins = c->ray_bins && cull == PTGPU_CULL_TIGHT && p.smask && c->math == PTGPU_MATH_FAST;
+    p.n_clusters = bins ? c->n_clusters : 0;
+    p.cmask = c->d_cmask;
+    p.cbounds = c->d_cbounds;
     return p;
 }
 
@@ -178,6 +191,10 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
 struct ShadowTables {
     std::vector<float4> sprims;
     std::vector<int> prim_of_slot;   // shadow-order slot -> primitive index, -1 for a filler
+    std::vector<int> cluster_of;     // primitive -> triangle cluster or -1
+    std::vector<float4> cluster_bounds;              // (centre, padded radius) per cluster
+    std::vector<unsigned long long> cluster_masks;   // (1 + clusters) x mw_tri words
+    std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
     std::vector<unsigned long long> safe, tight;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
     double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
@@ -231,22 +248,117 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
     return keep;
 }
 
+// Triangle clusters for the fast build's ray binning (device_params.h): connected components of
+// triangles that share a vertex position, the kMaxClusters largest with at least kMinClusterTris
+// triangles.  cluster_of[i] = cluster of primitive i or -1.
+constexpr int kMaxClusters = 8, kMinClusterTris = 8;
+std::vector<int> find_clusters(const std::vector<float4> &prims, const std::vector<int> &types,
+                               std::vector<float4> &bounds) {
+    const size_t n = types.size();
+    std::vector<int> parent(n);
+    for (size_t i = 0; i < n; ++i) parent[i] = (int)i;
+    auto find = [&](int x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    struct Key {
+        uint32_t x, y, z;
+        bool operator<(const Key &o) const { return x != o.x ? x < o.x : y != o.y ? y < o.y : z < o.z; }
+    };
+    std::map<Key, int> first_user;
+    auto corners = [&](size_t i, float4 v[3]) {
+        const float4 a = prims[3 * i], e1 = prims[3 * i + 1], e2 = prims[3 * i + 2];
+        v[0] = a;
+        v[1] = make_float4(a.x + e1.x, a.y + e1.y, a.z + e1.z, 0.f); // = p2, p3 up to one rounding: enough to
+        v[2] = make_float4(a.x + e2.x, a.y + e2.y, a.z + e2.z, 0.f); // bound; sharing is tested on p1 + e below
+    };
+    for (size_t i = 0; i < n; ++i) {
+        if (types[i] != PT_TRIANGLE) continue;
+        float4 v[3];
+        corners(i, v);
+        for (const float4 &c : v) {
+            // quantise to ~1e-5 relative so that p1 + (p2 - p1) still meets the neighbour's p2
+            auto q = [](float f) { return (uint32_t)(as_int(f) + 0x40) & ~0x7fu; };
+            const Key k{q(c.x), q(c.y), q(c.z)};
+            auto it = first_user.find(k);
+            if (it == first_user.end()) first_user.emplace(k, (int)i);
+            else parent[find((int)i)] = find(it->second);
+        }
+    }
+    std::map<int, int> size_of;
+    for (size_t i = 0; i < n; ++i)
+        if (types[i] == PT_TRIANGLE) size_of[find((int)i)]++;
+    std::vector<std::pair<int, int>> big; // (-size, root)
+    for (auto &kv : size_of)
+        if (kv.second >= kMinClusterTris) big.push_back({-kv.second, kv.first});
+    std::sort(big.begin(), big.end());
+    if ((int)big.size() > kMaxClusters) big.resize(kMaxClusters);
+    std::map<int, int> id_of;
+    for (size_t k = 0; k < big.size(); ++k) id_of[big[k].second] = (int)k;
+    std::vector<int> cluster_of(n, -1);
+    std::vector<D3> lo(big.size(), D3{1e300, 1e300, 1e300}), hi(big.size(), D3{-1e300, -1e300, -1e300});
+    for (size_t i = 0; i < n; ++i) {
+        if (types[i] != PT_TRIANGLE) continue;
+        auto it = id_of.find(find((int)i));
+        if (it == id_of.end()) continue;
+        const int c = cluster_of[i] = it->second;
+        float4 v[3];
+        corners(i, v);
+        for (const float4 &p : v) {
+            lo[c] = {std::min(lo[c].x, (double)p.x), std::min(lo[c].y, (double)p.y), std::min(lo[c].z, (double)p.z)};
+            hi[c] = {std::max(hi[c].x, (double)p.x), std::max(hi[c].y, (double)p.y), std::max(hi[c].z, (double)p.z)};
+        }
+    }
+    bounds.clear();
+    for (size_t c = 0; c < big.size(); ++c) {
+        const D3 mid{(lo[c].x + hi[c].x) / 2, (lo[c].y + hi[c].y) / 2, (lo[c].z + hi[c].z) / 2};
+        double r = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (cluster_of[i] != (int)c) continue;
+            float4 v[3];
+            corners(i, v);
+            for (const float4 &p : v) r = std::max(r, len(sub(d3(p), mid)));
+        }
+        // padded far beyond any rounding of the triangle test or of the segment test below; a NaN
+        // or infinite bound makes the device test pass for every ray (comparisons written that way)
+        r = r * 1.001 + 10 * (double)PT_EPSILON;
+        bounds.push_back(make_float4((float)mid.x, (float)mid.y, (float)mid.z, (float)r));
+    }
+    return cluster_of;
+}
+
 void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int> &types,
                          const std::vector<float4> &lights, ShadowTables &t) {
-    std::vector<int> sph, tri;
-    for (size_t i = 0; i < types.size(); ++i) (types[i] == PT_SPHERE ? sph : tri).push_back((int)i);
-    t.sg_sph = (int)((sph.size() + kSphereGroup - 1) / kSphereGroup);
-    t.sg_tri = (int)((tri.size() + kTriGroup - 1) / kTriGroup);
+    t.cluster_of = find_clusters(prims, types, t.cluster_bounds);
+    const int n_clusters = (int)t.cluster_bounds.size();
+    // shadow order: spheres; then the triangles of cluster 0, 1, ... each padded to whole groups;
+    // then the unclustered triangles.  slots[] = primitive index or -1 for a never-hit filler.
+    std::vector<int> sph_slots, tri_slots;
+    auto pad = [](std::vector<int> &v, int g) { while (v.size() % g) v.push_back(-1); };
+    for (size_t i = 0; i < types.size(); ++i)
+        if (types[i] == PT_SPHERE) sph_slots.push_back((int)i);
+    pad(sph_slots, kSphereGroup);
+    std::vector<std::pair<int, int>> cluster_groups(n_clusters); // [first group, end group) in triangle groups
+    for (int c = 0; c <= n_clusters; ++c) {
+        const int want = c < n_clusters ? c : -1;
+        const int begin = (int)tri_slots.size() / kTriGroup;
+        for (size_t i = 0; i < types.size(); ++i)
+            if (types[i] == PT_TRIANGLE && t.cluster_of[i] == want) tri_slots.push_back((int)i);
+        pad(tri_slots, kTriGroup);
+        if (c < n_clusters) cluster_groups[c] = {begin, (int)tri_slots.size() / kTriGroup};
+    }
+    t.sg_sph = (int)sph_slots.size() / kSphereGroup;
+    t.sg_tri = (int)tri_slots.size() / kTriGroup;
     t.mw_sph = (t.sg_sph + 63) / 64;
     t.mw_tri = (t.sg_tri + 63) / 64;
     const float ninf = -__builtin_inff();
     // never-hit fillers: a sphere with radius^2 = -inf (NaN discriminant fails every compare) and a
     // triangle with zero edges (0 * inf = NaN barycentrics and distance, "t > EPSILON" fails)
-    auto put = [&](const std::vector<int> &ids, int groups, bool sphere) {
-        for (int k = 0; k < (sphere ? kSphereGroup : kTriGroup) * groups; ++k) {
-            t.prim_of_slot.push_back(k < (int)ids.size() ? ids[k] : -1);
-            if (k < (int)ids.size()) {
-                for (int q = 0; q < 3; ++q) t.sprims.push_back(prims[3 * ids[k] + q]);
+    auto put = [&](const std::vector<int> &slots, bool sphere) {
+        for (int id : slots) {
+            t.prim_of_slot.push_back(id);
+            if (id >= 0) {
+                for (int q = 0; q < 3; ++q) t.sprims.push_back(prims[3 * id + q]);
             } else {
                 t.sprims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
                 t.sprims.push_back(sphere ? make_float4(ninf, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -254,8 +366,17 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
             }
         }
     };
-    put(sph, t.sg_sph, true);
-    put(tri, t.sg_tri, false);
+    put(sph_slots, true);
+    put(tri_slots, false);
+
+    // cluster_masks: row 0 = triangle groups outside every cluster, row 1 + c = groups of cluster c
+    t.cluster_masks.assign((size_t)(n_clusters + 1) * t.mw_tri, 0ull);
+    for (int g = 0; g < t.sg_tri; ++g) {
+        int row = 0;
+        for (int c = 0; c < n_clusters; ++c)
+            if (g >= cluster_groups[c].first && g < cluster_groups[c].second) row = 1 + c;
+        t.cluster_masks[(size_t)row * t.mw_tri + g / 64] |= 1ull << (g % 64);
+    }
 
     const size_t n_lights = lights.size() / 4, n_prims = types.size();
     const int words = t.mw_sph + t.mw_tri;
@@ -264,11 +385,11 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         out.assign(n_lights * words, 0ull);
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
-            for (size_t k = 0; k < sph.size(); ++k)
-                if (keep[l * n_prims + sph[k]])
+            for (size_t k = 0; k < sph_slots.size(); ++k)
+                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]])
                     out[l * words + (k / kSphereGroup) / 64] |= 1ull << ((k / kSphereGroup) % 64);
-            for (size_t k = 0; k < tri.size(); ++k)
-                if (keep[l * n_prims + tri[k]])
+            for (size_t k = 0; k < tri_slots.size(); ++k)
+                if (tri_slots[k] >= 0 && keep[l * n_prims + tri_slots[k]])
                     out[l * words + t.mw_sph + (k / kTriGroup) / 64] |= 1ull << ((k / kTriGroup) % 64);
             for (int w = 0; w < words; ++w)
                 total += (w < t.mw_sph ? kSphereGroup : kTriGroup) * __builtin_popcountll(out[l * words + w]);
@@ -277,6 +398,14 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     };
     masks(PTGPU_CULL_SAFE, t.safe, t.mean_safe);
     masks(PTGPU_CULL_TIGHT, t.tight, t.mean_tight);
+
+    // per light: the clusters with a group in its TIGHT set (the ones a ray towards it is binned on)
+    t.light_clusters.assign(n_lights, 0u);
+    for (size_t l = 0; l < n_lights; ++l)
+        for (int c = 0; c < n_clusters; ++c)
+            for (int w = 0; w < t.mw_tri; ++w)
+                if (t.tight[l * words + t.mw_sph + w] & t.cluster_masks[(size_t)(1 + c) * t.mw_tri + w])
+                    t.light_clusters[l] |= 1u << c;
 }
 
 // The device-side records of ptgpu_set_scene (device_params.h); shared with ptgpu_shadow_candidates.
@@ -467,6 +596,9 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
             return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
         ctx->shadow_cull = value;
         return PTGPU_OK;
+    case PTGPU_OPT_RAY_BINS:
+        ctx->ray_bins = value ? 1 : 0;
+        return PTGPU_OK;
     case PTGPU_OPT_PASSES_PER_LAUNCH:
         if (value < 0 || value > 64) return fail(PTGPU_ERR_ARGUMENT, "passes per launch must be 0..64");
         ctx->passes_per_launch = value;
@@ -540,6 +672,9 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     // and stay small.
     ShadowTables st;
     build_shadow_tables(prims, types, lights, st);
+    if (info.lights >= (1u << 18)) st.cluster_bounds.clear(); // the near-queue tag holds 18 bits of light index
+    for (size_t l = 0; l < st.light_clusters.size(); ++l)   // l1.w is free in both light kinds
+        dlights[kLightQuads * l + 1].w = as_float(st.cluster_bounds.empty() ? 0 : (int)st.light_clusters[l]);
     std::vector<float4> sshade;
     for (int slot : st.prim_of_slot)
         for (int q = 0; q < 4; ++q) sshade.push_back(slot >= 0 ? shade[4 * slot + q] : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -552,7 +687,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     const size_t light_bytes = dlights.size() * sizeof(float4), shadow_bytes = st.sprims.size() * sizeof(float4);
     const uint32_t lds_strict = fits(prims.size() * sizeof(float4) + light_bytes);
     const uint32_t lds_strict_cull = fits(prims.size() * sizeof(float4) + light_bytes + shadow_bytes);
-    const uint32_t lds_fast = fits(shadow_bytes + light_bytes);
+    const uint32_t lds_fast = fits(shadow_bytes + light_bytes + st.cluster_bounds.size() * sizeof(float4));
     info.lds_bytes = lds_fast;
 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -573,7 +708,12 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     if (use_tables) {
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));
         HIP_TRY(upload(ctx->d_smask_tight, st.tight));
+        HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
+        HIP_TRY(upload(ctx->d_cbounds, st.cluster_bounds));
     }
+    ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
+    info.clusters = (uint32_t)ctx->n_clusters;
+    for (int c : st.cluster_of) info.clustered_triangles += (ctx->n_clusters && c >= 0) ? 1u : 0u;
     ctx->sg_sph = st.sg_sph;
     ctx->sg_tri = st.sg_tri;
     ctx->mw_sph = st.mw_sph;

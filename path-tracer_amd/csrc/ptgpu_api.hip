@@ -459,8 +459,11 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     // tail is covered by the other regions); a single region keeps 8 passes per launch.
     const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);
 
+    // AUTO: the shadow-ray queues pay with two or more lights and incoherent hit points; the direct
+    // lighting integrator stops at the (tile-coherent) first hit, where the inline loop is ahead
     const int kernel = c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
-                       : (c->info.lights >= 2 ? PTGPU_KERNEL_WAVEFRONT : PTGPU_KERNEL_MEGA);
+                       : (c->info.lights >= 2 && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
+                                                                                    : PTGPU_KERNEL_MEGA);
     auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
         if (kernel == PTGPU_KERNEL_MEGA)
             return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);

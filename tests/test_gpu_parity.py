@@ -30,10 +30,10 @@ KERNELS = [pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT]
 KNAME = {pt.KERNEL_MEGA: "mega", pt.KERNEL_WAVEFRONT: "wavefront"}
 
 
-def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False, cull=None):
+def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False, cull=None, bins=None):
     sc = pt.LoadedScene(name, w, h)
     seeds = pt.seed_block(w, h) if seeds is None else seeds
-    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds, shadow_cull=cull)
+    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds, shadow_cull=cull, ray_bins=bins)
     g.set_scene(sc)
     g.resize(w, h, seeds)
     if per_pass:
@@ -120,6 +120,42 @@ def test_shadow_cull_full_size_cornell_safe_is_brute_force():
     assert moved < 0.05                                       # the FP floor on cornell is ~50 %
     mean_off, mean_tight = off[0][ok].mean(), tight[0][ok].mean()
     assert abs(mean_tight - mean_off) <= 2e-3 * mean_off       # no energy drift
+
+
+@pytest.mark.parametrize("lds", [1, 0])
+@pytest.mark.parametrize("case", [("cornell", 160, 120, 8, 0), ("materials", 160, 120, 16, 0), ("cornell", 96, 72, 8, 1)])
+def test_ray_bins_do_not_change_the_fast_image(case, lds):
+    # Binning shadow rays on triangle clusters (fast build, wavefront kernel) only skips clusters whose
+    # padded bounding sphere the ray misses: the occluders found are the same.  What differs is
+    # rounding - a near-queue ray is rebuilt from its draws and its contribution is added with an LDS
+    # atomic instead of in light order - so the two images agree to float noise, not bit for bit.
+    name, w, h, spp, integ = case
+    on = gpu_render(name, w, h, spp, integ, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, lds=lds, bins=1)
+    off = gpu_render(name, w, h, spp, integ, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, lds=lds, bins=0)
+    assert (on[2] == off[2]).all()                              # same draws
+    nan_on, nan_off = np.isnan(on[0]).any(1), np.isnan(off[0]).any(1)
+    assert (nan_on == nan_off).all()
+    ok = ~nan_on
+    rel = np.abs(on[0][ok] - off[0][ok]).max(1) / np.maximum(np.abs(off[0][ok]).max(1), 1e-3)
+    print(f"{name}: bins on vs off, share of pixels off by > 1e-4 relative: {(rel > 1e-4).mean():.5f}, max {rel.max():.3g}")
+    assert (rel > 1e-4).mean() < 0.002
+    assert abs(on[0][ok].mean() - off[0][ok].mean()) <= 1e-5 * off[0][ok].mean()
+
+
+def test_scene_info_reports_shadow_tables_and_clusters():
+    g = pt.Gpu(0, 0)
+    g.set_scene(pt.LoadedScene("cornell", 32, 24))
+    info = g.scene_info()
+    assert (info["primitives"], info["spheres"], info["triangles"], info["lights"]) == (141, 6, 135, 123)
+    assert info["clusters"] == 2 and info["clustered_triangles"] == 135      # the cylinder and the cube
+    assert info["shadow_tests_tight"] < 0.15 * 141 < info["shadow_tests_safe"] < 0.7 * 141
+    g.set_scene(pt.LoadedScene("obj-model", 32, 24))                        # nothing to cull: no tables, no bins
+    info = g.scene_info()
+    assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 322
+    for opt, bad in ((pt.OPT_SHADOW_CULL, 4), (pt.OPT_SHADOW_CULL, -1), (9, 0)):
+        with pytest.raises(pt.GpuError):
+            g.set_option(opt, bad)
+    g.close()
 
 
 # floor RMSE between the two CPU builds of the reference, SURVEY.md 8-c calibration table

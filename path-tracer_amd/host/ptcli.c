@@ -37,7 +37,7 @@ int main(int argc, char *argv[]) {
     const char *scene_name = "scenes/stacked-spheres.txt", *kernel_file = "path-tracing.cl";
     const char *out_path = NULL, *model_dir = NULL;
     int width = 800, height = 600, spp = 64, device = 0, quiet = 0;
-    int integrator = -1, math = PTGPU_MATH_FAST, kernel = PTGPU_KERNEL_WAVEFRONT;
+    int integrator = -1, math = PTGPU_MATH_FAST, kernel = PTGPU_KERNEL_AUTO, cull = PTGPU_CULL_AUTO;
 
     int npos = 0;
     const char *pos[6];
@@ -50,12 +50,20 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(a, "--device") && v) { device = atoi(v); ++i; }
         else if (!strcmp(a, "--integrator") && v) { integrator = !strcmp(v, "dl") ? PT_INTEGRATOR_DL : PT_INTEGRATOR_PT; ++i; }
         else if (!strcmp(a, "--math") && v) { math = !strcmp(v, "strict") ? PTGPU_MATH_STRICT : PTGPU_MATH_FAST; ++i; }
-        else if (!strcmp(a, "--kernel") && v) { kernel = !strcmp(v, "mega") ? PTGPU_KERNEL_MEGA : PTGPU_KERNEL_WAVEFRONT; ++i; }
+        else if (!strcmp(a, "--kernel") && v) {
+            kernel = !strcmp(v, "mega") ? PTGPU_KERNEL_MEGA : !strcmp(v, "wavefront") ? PTGPU_KERNEL_WAVEFRONT : PTGPU_KERNEL_AUTO;
+            ++i;
+        } else if (!strcmp(a, "--cull") && v) {
+            cull = !strcmp(v, "off") ? PTGPU_CULL_OFF : !strcmp(v, "safe") ? PTGPU_CULL_SAFE
+                   : !strcmp(v, "tight") ? PTGPU_CULL_TIGHT : PTGPU_CULL_AUTO;
+            ++i;
+        }
         else if (!strcmp(a, "--quiet")) quiet = 1;
         else if (a[0] == '-' && a[1] == '-') {
             fprintf(stderr, "Usage: %s [<use CPU/GPU device> <workgroup size> <kernel file name> <window width> "
                             "<window height> <scene file>] [--spp N] [--out image.ppm] [--integrator pt|dl] "
-                            "[--math fast|strict] [--kernel wavefront|mega] [--models DIR] [--device N]\n", argv[0]);
+                            "[--math fast|strict] [--kernel auto|wavefront|mega] [--cull auto|off|safe|tight] [--models DIR] "
+                            "[--device N]\n", argv[0]);
             exit(-1);
         } else if (npos < 6) pos[npos++] = a;
     }
@@ -88,7 +96,8 @@ int main(int argc, char *argv[]) {
 
     ptgpu_ctx *ctx = NULL;
     if (ptgpu_create(&ctx, device, integrator)) die_gpu("Failed to create the device context");
-    if (ptgpu_set_option(ctx, PTGPU_OPT_MATH, math) || ptgpu_set_option(ctx, PTGPU_OPT_KERNEL, kernel))
+    if (ptgpu_set_option(ctx, PTGPU_OPT_MATH, math) || ptgpu_set_option(ctx, PTGPU_OPT_KERNEL, kernel) ||
+        ptgpu_set_option(ctx, PTGPU_OPT_SHADOW_CULL, cull))
         die_gpu("Failed to set an option");
     if (ptgpu_set_scene(ctx, sc.objects, sc.object_count, sc.light_count, sc.materials,
                         sc.scene.material_count, &sc.scene))

@@ -48,9 +48,19 @@ enum {
     PTGPU_OPT_WAVES_PER_GROUP = 5,   /* wavefront kernel: waves per workgroup, 1..16; 0 = default */
     PTGPU_OPT_SHADOW_CULL = 6,       /* PTGPU_CULL_* (default AUTO): which primitives a shadow ray
                                         towards a one-sided triangle light is tested against     */
-    PTGPU_OPT_RAY_BINS = 7           /* 1 (default) = fast build with TIGHT sets bins shadow rays on
+    PTGPU_OPT_RAY_BINS = 7,          /* 1 (default) = fast build with TIGHT sets bins shadow rays on
                                         triangle clusters (wavefront kernel); 0 = one queue        */
+    PTGPU_OPT_BVH = 8                /* PTGPU_BVH_* (default AUTO)                                  */
 };
+/* Intersect / IntersectP (geomfunc.h:126-193) scan every object.  For a scene whose cost is that
+ * scan over one large mesh the kernels can walk a bounding-volume hierarchy instead (each lane its
+ * own way, nodes and leaves in LDS).  A primitive is skipped only when the ray misses a padded box
+ * around it or enters the box beyond the closest hit so far, and the closest hit is chosen by
+ * (distance, object index): the result is the linear scan's, whatever the visiting order.
+ *   AUTO = on when the per-light candidate sets do not apply to the scene and the hierarchy holds
+ *          at least 64 primitives (obj-model.txt, large-object.txt, complex.txt ...);
+ *   ON   = on whenever a hierarchy could be built (>= 8 primitives); the candidate sets are then off. */
+enum { PTGPU_BVH_OFF = 0, PTGPU_BVH_ON = 1, PTGPU_BVH_AUTO = 2 };
 enum {
     PTGPU_KERNEL_MEGA      = 0, /* one thread = one pixel = one whole path; the direct counterpart of
                                    the reference kernel's shape, kept as the measured baseline  */
@@ -164,6 +174,8 @@ typedef struct ptgpu_scene_info {
     float    shadow_tests_tight;   /* same under TIGHT; equals `primitives` padded when nothing is culled */
     uint32_t clusters;             /* triangle clusters the fast build bins shadow rays on (0..8) */
     uint32_t clustered_triangles;  /* triangles inside them */
+    uint32_t bvh_nodes;            /* nodes of the hierarchy built for PTGPU_OPT_BVH (0 = none) */
+    uint32_t bvh_primitives;       /* primitives inside it; the others are scanned one by one */
 } ptgpu_scene_info;
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 

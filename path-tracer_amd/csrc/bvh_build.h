@@ -1,0 +1,188 @@
+// bvh_build.h - host-side builder of the threaded bounding-volume hierarchy (device_params.h,
+// "BVH").  Included by ptgpu_api.hip only.
+//
+// The reference scans every object for every ray (geomfunc.h:126-193).  For scenes whose cost is
+// that scan over one large mesh (obj-model.txt, large-object.txt, complex.txt) the kernels may walk
+// a hierarchy instead; a primitive is skipped only when the ray misses a padded box around it or
+// enters that box beyond the closest hit found so far, and the closest hit is chosen by
+// (distance, object index), so the result does not depend on the visiting order: it is the
+// reference's.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "pt_records.h"
+
+namespace ptbvh {
+
+constexpr int kLeaf = 4; // primitives per leaf, padded with never-hit records
+
+struct Box {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    void grow(const double p[3]) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void grow(const Box &b) {
+        grow(b.lo);
+        grow(b.hi);
+    }
+    double area() const {
+        const double x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return x < 0 ? 0 : 2 * (x * y + y * z + z * x);
+    }
+};
+
+struct Built {
+    int type = -1;                   // PT_SPHERE or PT_TRIANGLE: the primitive type inside the hierarchy
+    std::vector<float4> nodes;       // 2 quads per node: (lo.xyz, skip index) (hi.xyz, leaf: first primitive | inner: -1)
+    std::vector<float4> prims;       // 3 quads per primitive slot, leaf order, kLeaf slots per leaf
+    std::vector<int> prim_of_slot;   // slot -> primitive index (index order), -1 for a filler
+    std::vector<int> rest;           // primitives of the other type (and non-finite ones): scanned one by one
+};
+
+inline int float_bits(float f) {
+    int v;
+    memcpy(&v, &f, sizeof v);
+    return v;
+}
+inline float bits_float(int v) {
+    float f;
+    memcpy(&f, &v, sizeof f);
+    return f;
+}
+
+// prims: 3 quads per primitive in index order (device_params.h); types[i]: PT_SPHERE / PT_TRIANGLE.
+inline Built build(const std::vector<float4> &prims, const std::vector<int> &types) {
+    Built out;
+    const size_t n = types.size();
+    size_t n_sph = 0;
+    for (int t : types) n_sph += t == PT_SPHERE;
+    out.type = n_sph > n - n_sph ? PT_SPHERE : PT_TRIANGLE;
+
+    std::vector<Box> boxes(n);
+    std::vector<int> order;
+    for (size_t i = 0; i < n; ++i) {
+        Box b;
+        bool finite = true;
+        if (types[i] == PT_SPHERE) {
+            const float4 c = prims[3 * i];
+            const double r = std::fabs((double)c.w);
+            const double lo[3] = {c.x - r, c.y - r, c.z - r}, hi[3] = {c.x + r, c.y + r, c.z + r};
+            b.grow(lo);
+            b.grow(hi);
+        } else {
+            const float4 a = prims[3 * i], e1 = prims[3 * i + 1], e2 = prims[3 * i + 2];
+            const double v[3][3] = {{a.x, a.y, a.z},
+                                    {(double)a.x + e1.x, (double)a.y + e1.y, (double)a.z + e1.z},
+                                    {(double)a.x + e2.x, (double)a.y + e2.y, (double)a.z + e2.z}};
+            for (auto &p : v) b.grow(p);
+        }
+        for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
+        // pad far beyond the rounding of the primitive tests: 1e-4 of the extent and position + 10 EPSILON
+        for (int a = 0; a < 3; ++a) {
+            const double pad = 1e-4 * ((b.hi[a] - b.lo[a]) + std::fabs(b.lo[a]) + std::fabs(b.hi[a])) + 10 * (double)PT_EPSILON;
+            b.lo[a] -= pad;
+            b.hi[a] += pad;
+        }
+        boxes[i] = b;
+        if (types[i] == out.type && finite) order.push_back((int)i);
+        else out.rest.push_back((int)i);
+    }
+
+    struct Task { int begin, end; };
+    // recursive median-of-SAH-bins build over order[begin, end), emitting nodes in preorder
+    std::vector<int> leaf_first; // per node: first slot or -1
+    std::vector<Box> node_box;
+    std::vector<int> skip;
+    std::function<void(int, int)> rec = [&](int begin, int end) {
+        const int me = (int)node_box.size();
+        Box nb, cb;
+        for (int k = begin; k < end; ++k) {
+            nb.grow(boxes[order[k]]);
+            const Box &b = boxes[order[k]];
+            const double c[3] = {(b.lo[0] + b.hi[0]) / 2, (b.lo[1] + b.hi[1]) / 2, (b.lo[2] + b.hi[2]) / 2};
+            cb.grow(c);
+        }
+        node_box.push_back(nb);
+        leaf_first.push_back(-1);
+        skip.push_back(0);
+        if (end - begin <= kLeaf) {
+            leaf_first[me] = (int)out.prim_of_slot.size();
+            for (int k = 0; k < kLeaf; ++k) out.prim_of_slot.push_back(k < end - begin ? order[begin + k] : -1);
+            skip[me] = (int)node_box.size();
+            return;
+        }
+        // binned SAH on the widest centroid axis
+        int axis = 0;
+        for (int a = 1; a < 3; ++a)
+            if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+        int mid = (begin + end) / 2;
+        const double width = cb.hi[axis] - cb.lo[axis];
+        auto centre = [&](int i) { return (boxes[i].lo[axis] + boxes[i].hi[axis]) / 2; };
+        if (width > 0) {
+            constexpr int kBins = 16;
+            Box bin_box[kBins];
+            int bin_n[kBins] = {};
+            auto bin_of = [&](int i) { return std::min(kBins - 1, (int)((centre(i) - cb.lo[axis]) / width * kBins)); };
+            for (int k = begin; k < end; ++k) {
+                bin_box[bin_of(order[k])].grow(boxes[order[k]]);
+                bin_n[bin_of(order[k])]++;
+            }
+            double best = 1e300;
+            int best_split = -1;
+            for (int s = 1; s < kBins; ++s) {
+                Box l, r;
+                int nl = 0, nr = 0;
+                for (int b = 0; b < s; ++b) if (bin_n[b]) { l.grow(bin_box[b]); nl += bin_n[b]; }
+                for (int b = s; b < kBins; ++b) if (bin_n[b]) { r.grow(bin_box[b]); nr += bin_n[b]; }
+                if (!nl || !nr) continue;
+                // leaves hold kLeaf slots: count whole leaves
+                const double cost = l.area() * ((nl + kLeaf - 1) / kLeaf) + r.area() * ((nr + kLeaf - 1) / kLeaf);
+                if (cost < best) { best = cost; best_split = s; }
+            }
+            if (best_split > 0) {
+                auto it = std::stable_partition(order.begin() + begin, order.begin() + end,
+                                                [&](int i) { return bin_of(i) < best_split; });
+                mid = (int)(it - order.begin());
+            }
+        }
+        if (mid <= begin || mid >= end) { // all centroids equal: split by count
+            std::stable_sort(order.begin() + begin, order.begin() + end, [&](int x, int y) { return centre(x) < centre(y); });
+            mid = (begin + end) / 2;
+        }
+        rec(begin, mid);
+        rec(mid, end);
+        skip[me] = (int)node_box.size();
+    };
+    if (!order.empty()) rec(0, (int)order.size());
+
+    const float ninf = -__builtin_inff();
+    for (int id : out.prim_of_slot) {
+        if (id >= 0) {
+            for (int q = 0; q < 3; ++q) out.prims.push_back(prims[3 * id + q]);
+        } else { // never-hit fillers, as in the shadow order
+            out.prims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+            out.prims.push_back(out.type == PT_SPHERE ? make_float4(ninf, 0.f, 0.f, 0.f) : make_float4(0.f, 0.f, 0.f, 0.f));
+            out.prims.push_back(make_float4(0.f, 0.f, 0.f, 0.f));
+        }
+    }
+    auto down = [](double v) { return std::nextafter((float)v, -INFINITY) ; };
+    auto up = [](double v) { return std::nextafter((float)v, INFINITY); };
+    for (size_t i = 0; i < node_box.size(); ++i) {
+        const Box &b = node_box[i];
+        out.nodes.push_back(make_float4(down(b.lo[0]), down(b.lo[1]), down(b.lo[2]), bits_float(skip[i])));
+        out.nodes.push_back(make_float4(up(b.hi[0]), up(b.hi[1]), up(b.hi[2]), bits_float(leaf_first[i])));
+    }
+    return out;
+}
+
+} // namespace ptbvh

@@ -32,6 +32,17 @@
 //   smask  [n_lights * (mw_sph + mw_tri)]  per light, 64-bit words: bit g of the first mw_sph words
 //                          = sphere group g may occlude a shadow ray towards this light; the next
 //                          mw_tri words the same for triangle groups.
+//
+// BVH (optional, PTGPU_OPT_BVH; built by bvh_build.h): one array `bvh` of quads
+//   [2 * n_bnodes]  nodes in depth-first order: (lo.xyz, skip) (hi.xyz, first) - a ray that misses
+//                   the padded box continues at node `skip`; otherwise at the next node, or, when
+//                   first >= 0, tests the 4 primitive slots first .. first + 3 and continues at `skip`
+//   [3 * n_bslots]  primitive records of ONE type (bvh_type) in leaf order, never-hit fillers included
+//   [3 * n_brest]   the other primitives, scanned one by one; the type is in the third quad's w
+// bvh_ids[slot] / bvh_rest_ids[r] = the primitive's index in the build's own numbering (index order
+// for the strict build, shadow order for the fast build): what load_surface takes and what breaks
+// a tie between equal distances.  While the BVH is active the block is staged in LDS in place of
+// the build's primary primitive array and the per-light candidate sets are off.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -71,6 +82,10 @@ struct PtDeviceParams {
                                       // cluster, row 1 + c = groups of cluster c
     const float4 *cbounds;            // n_clusters x (centre, padded radius), staged after the lights
     int n_clusters;
+    // BVH; n_bnodes == 0 switches it off
+    const float4 *bvh;
+    const int *bvh_ids, *bvh_rest_ids;
+    int n_bnodes, n_bslots, n_brest, bvh_type;
 };
 
 struct PtLaunchConfig {

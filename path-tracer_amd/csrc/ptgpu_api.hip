@@ -14,6 +14,7 @@
 #include <cstring>
 #include <vector>
 
+#include "bvh_build.h"
 #include "device_params.h"
 #include "ptgpu.h"
 
@@ -60,6 +61,7 @@ struct ptgpu_ctx {
     int waves_per_group = 0;          // 0 = default (PTGPU_OPT_WAVES_PER_GROUP)
     int shadow_cull = PTGPU_CULL_AUTO; // PTGPU_OPT_SHADOW_CULL
     int ray_bins = 1;                  // PTGPU_OPT_RAY_BINS
+    int bvh = PTGPU_BVH_AUTO;          // PTGPU_OPT_BVH
     hipStream_t stream = nullptr;     // the context's stream: everything is ordered on it
     hipStream_t side[kMaxStreams - 1] = {};
     hipEvent_t fork_ev = nullptr, join_ev[kMaxStreams - 1] = {};
@@ -72,6 +74,12 @@ struct ptgpu_ctx {
     float4 *d_sprims = nullptr, *d_sshade = nullptr;
     unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_cmask = nullptr;
     float4 *d_cbounds = nullptr;
+    // BVH (device_params.h): one block + the id tables in each build's numbering
+    float4 *d_bvh = nullptr;
+    int *d_bvh_ids_index = nullptr, *d_bvh_ids_slot = nullptr, *d_bvh_rest_index = nullptr, *d_bvh_rest_slot = nullptr;
+    int n_bnodes = 0, n_bslots = 0, n_brest = 0, bvh_type = 0;
+    bool bvh_auto = false;             // AUTO turns it on for this scene
+    uint32_t lds_bvh = 0;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
     uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
@@ -106,6 +114,13 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_cbounds) (void)hipFree(c->d_cbounds);
     c->d_cmask = nullptr;
     c->d_cbounds = nullptr;
+    if (c->d_bvh) (void)hipFree(c->d_bvh);
+    for (int **q : {&c->d_bvh_ids_index, &c->d_bvh_ids_slot, &c->d_bvh_rest_index, &c->d_bvh_rest_slot}) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
+    c->d_bvh = nullptr;
+    c->n_bnodes = c->n_bslots = c->n_brest = 0;
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     c->d_sprims = nullptr;
@@ -184,6 +199,19 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.n_clusters = bins ? c->n_clusters : 0;
     p.cmask = c->d_cmask;
     p.cbounds = c->d_cbounds;
+    const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
+    if (use_bvh) { // the hierarchy replaces the candidate sets
+        p.smask = nullptr;
+        p.n_clusters = 0;
+        p.bvh = c->d_bvh;
+        const bool strict = c->math == PTGPU_MATH_STRICT;
+        p.bvh_ids = strict ? c->d_bvh_ids_index : c->d_bvh_ids_slot;
+        p.bvh_rest_ids = strict ? c->d_bvh_rest_index : c->d_bvh_rest_slot;
+        p.n_bnodes = c->n_bnodes;
+        p.n_bslots = c->n_bslots;
+        p.n_brest = c->n_brest;
+        p.bvh_type = c->bvh_type;
+    }
     return p;
 }
 
@@ -446,7 +474,10 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     if (n_passes == 0) return PTGPU_OK;
     PtLaunchConfig cfg{};
     PtDeviceParams probe = make_params(c, first_sample, 1);
-    const uint32_t stage_bytes = c->math == PTGPU_MATH_FAST ? c->lds_fast : probe.smask ? c->lds_strict_cull : c->lds_strict;
+    const uint32_t stage_bytes = probe.n_bnodes            ? c->lds_bvh
+                                 : c->math == PTGPU_MATH_FAST ? c->lds_fast
+                                 : probe.smask               ? c->lds_strict_cull
+                                                             : c->lds_strict;
     cfg.use_lds = c->want_lds && stage_bytes > 0;
     cfg.lds_bytes = cfg.use_lds ? stage_bytes : 0;
     cfg.waves_per_group = c->waves_per_group;
@@ -599,6 +630,10 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
             return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
         ctx->shadow_cull = value;
         return PTGPU_OK;
+    case PTGPU_OPT_BVH:
+        if (value < PTGPU_BVH_OFF || value > PTGPU_BVH_AUTO) return fail(PTGPU_ERR_ARGUMENT, "unknown BVH mode %d", value);
+        ctx->bvh = value;
+        return PTGPU_OK;
     case PTGPU_OPT_RAY_BINS:
         ctx->ray_bins = value ? 1 : 0;
         return PTGPU_OK;
@@ -693,6 +728,37 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     const uint32_t lds_fast = fits(shadow_bytes + light_bytes + st.cluster_bounds.size() * sizeof(float4));
     info.lds_bytes = lds_fast;
 
+    // BVH: built for every scene with something to gain; AUTO uses it when the candidate sets do
+    // not apply and the hierarchy's primitive type has at least 64 members
+    ptbvh::Built bvh;
+    std::vector<float4> bvh_block;
+    std::vector<int> ids_index, ids_slot, rest_index, rest_slot;
+    if (info.primitives >= 8 && info.primitives < (1u << 24)) {
+        bvh = ptbvh::build(prims, types);
+        std::vector<int> slot_of_prim(types.size(), -1);
+        for (size_t k = 0; k < st.prim_of_slot.size(); ++k)
+            if (st.prim_of_slot[k] >= 0) slot_of_prim[st.prim_of_slot[k]] = (int)k;
+        bvh_block = bvh.nodes;
+        bvh_block.insert(bvh_block.end(), bvh.prims.begin(), bvh.prims.end());
+        for (int id : bvh.prim_of_slot) {
+            ids_index.push_back(id >= 0 ? id : 0x7fffffff);
+            ids_slot.push_back(id >= 0 ? slot_of_prim[id] : 0x7fffffff);
+        }
+        for (int id : bvh.rest) {
+            bvh_block.push_back(prims[3 * id]);
+            bvh_block.push_back(prims[3 * id + 1]);
+            float4 c = prims[3 * id + 2];
+            c.w = as_float(types[id]);
+            bvh_block.push_back(c);
+            rest_index.push_back(id);
+            rest_slot.push_back(slot_of_prim[id]);
+        }
+    }
+    const size_t in_tree = bvh.prim_of_slot.size() ? types.size() - bvh.rest.size() : 0;
+    const uint32_t lds_bvh = fits(bvh_block.size() * sizeof(float4) + light_bytes);
+    info.bvh_nodes = (uint32_t)(bvh.nodes.size() / 2);
+    info.bvh_primitives = (uint32_t)in_tree;
+
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_scene(ctx);
     auto upload = [&](auto *&dst, const auto &src) -> hipError_t {
@@ -714,6 +780,19 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
         HIP_TRY(upload(ctx->d_cbounds, st.cluster_bounds));
     }
+    if (!bvh.nodes.empty()) {
+        HIP_TRY(upload(ctx->d_bvh, bvh_block));
+        HIP_TRY(upload(ctx->d_bvh_ids_index, ids_index));
+        HIP_TRY(upload(ctx->d_bvh_ids_slot, ids_slot));
+        HIP_TRY(upload(ctx->d_bvh_rest_index, rest_index));
+        HIP_TRY(upload(ctx->d_bvh_rest_slot, rest_slot));
+        ctx->n_bnodes = (int)(bvh.nodes.size() / 2);
+        ctx->n_bslots = (int)bvh.prim_of_slot.size();
+        ctx->n_brest = (int)bvh.rest.size();
+        ctx->bvh_type = bvh.type;
+    }
+    ctx->bvh_auto = !use_tables && in_tree >= 64 && bvh.rest.size() <= 64;
+    ctx->lds_bvh = lds_bvh;
     ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
     info.clusters = (uint32_t)ctx->n_clusters;
     for (int c : st.cluster_of) info.clustered_triangles += (ctx->n_clusters && c >= 0) ? 1u : 0u;

@@ -220,6 +220,8 @@ def obj_parse(data: bytes):
 OPT_KERNEL, OPT_MATH, OPT_LDS, OPT_STREAMS, OPT_PASSES_PER_LAUNCH, OPT_WAVES_PER_GROUP = 0, 1, 2, 3, 4, 5
 OPT_SHADOW_CULL = 6
 OPT_RAY_BINS = 7
+OPT_BVH = 8
+BVH_OFF, BVH_ON, BVH_AUTO = 0, 1, 2
 CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO = 0, 1, 2, 3
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
@@ -230,7 +232,8 @@ class SceneInfo(C.Structure):
     _fields_ = ([(n, C.c_uint32) for n in ("primitives", "spheres", "triangles", "lights", "segments",
                                           "lds_bytes", "shadow_groups")]
                 + [("shadow_tests_safe", C.c_float), ("shadow_tests_tight", C.c_float),
-                   ("clusters", C.c_uint32), ("clustered_triangles", C.c_uint32)])
+                   ("clusters", C.c_uint32), ("clustered_triangles", C.c_uint32),
+                   ("bvh_nodes", C.c_uint32), ("bvh_primitives", C.c_uint32)])
 
 
 GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_scene", "ptgpu_set_camera",
@@ -295,7 +298,7 @@ class Gpu:
     """One ptgpu context driven the way main-gpu.c drives its OpenCL objects."""
 
     def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None, streams=None,
-                 passes_per_launch=None, waves_per_group=None, shadow_cull=None, ray_bins=None):
+                 passes_per_launch=None, waves_per_group=None, shadow_cull=None, ray_bins=None, bvh=None):
         self.lib = gpu()
         self.ctx = C.c_void_p()
         self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
@@ -315,6 +318,8 @@ class Gpu:
             self.set_option(OPT_SHADOW_CULL, shadow_cull)
         if ray_bins is not None:
             self.set_option(OPT_RAY_BINS, ray_bins)
+        if bvh is not None:
+            self.set_option(OPT_BVH, bvh)
         self.w = self.h = 0
         self.sample = 0
 

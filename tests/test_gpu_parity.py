@@ -30,10 +30,11 @@ KERNELS = [pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT]
 KNAME = {pt.KERNEL_MEGA: "mega", pt.KERNEL_WAVEFRONT: "wavefront"}
 
 
-def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False, cull=None, bins=None):
+def gpu_render(name, w, h, spp, integrator, kernel, math, lds=1, seeds=None, per_pass=False, cull=None, bins=None,
+               bvh=None):
     sc = pt.LoadedScene(name, w, h)
     seeds = pt.seed_block(w, h) if seeds is None else seeds
-    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds, shadow_cull=cull, ray_bins=bins)
+    g = pt.Gpu(0, integrator, kernel=kernel, math=math, lds=lds, shadow_cull=cull, ray_bins=bins, bvh=bvh)
     g.set_scene(sc)
     g.resize(w, h, seeds)
     if per_pass:
@@ -73,6 +74,44 @@ def test_strict_is_bit_exact_against_oracle(case, lds, kernel):
     assert (sd == cpu.seeds).all()
     assert same_bits(colors, cpu.colors)
     assert (pixels == cpu.pixels).all()
+
+
+# BVH (PTGPU_OPT_BVH): forced on for every golden case, the strict build must still reproduce the
+# reference bit for bit - every closest hit (distance bits and object, ties included) and every
+# occlusion answer of the render equals the linear scan's.
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("fn", golden_cases())
+def test_bvh_strict_is_bit_exact_against_reference_golden(fn, kernel):
+    g = load_golden(fn)
+    colors, pixels, seeds = gpu_render(g["scene"], g["w"], g["h"], g["spp"], g["integrator"], kernel,
+                                       pt.MATH_STRICT, bvh=pt.BVH_ON)
+    assert (seeds == g["seeds_after"]).all()
+    assert same_bits(colors, g["colors"])
+    assert (pixels == g["pixels"]).all()
+
+
+@pytest.mark.parametrize("lds", [1, 0])
+@pytest.mark.parametrize("name", ["obj-model", "large-object", "complex", "table-and-mirror", "cornell"])
+def test_bvh_full_size_equals_linear_scan(name, lds):
+    # 1024x768: ~10^7 extension rays and as many shadow rays per pass through the hierarchy
+    w, h, spp = 1024, 768, 2
+    off = gpu_render(name, w, h, spp, 0, pt.KERNEL_MEGA, pt.MATH_STRICT, lds=lds, bvh=pt.BVH_OFF, cull=pt.CULL_OFF)
+    on = gpu_render(name, w, h, spp, 0, pt.KERNEL_MEGA, pt.MATH_STRICT, lds=lds, bvh=pt.BVH_ON)
+    assert same_bits(off[0], on[0]) and (off[1] == on[1]).all() and (off[2] == on[2]).all()
+
+
+def test_bvh_auto_choice_and_fast_build():
+    g = pt.Gpu(0, 0)
+    for name, expect_tree in (("obj-model", 322), ("large-object", 968), ("complex", 783)):
+        g.set_scene(pt.LoadedScene(name, 32, 24))
+        info = g.scene_info()
+        assert info["bvh_primitives"] == expect_tree and info["bvh_nodes"] > expect_tree // 4
+    g.close()
+    # fast build: BVH on vs off agree to the calibrated floor (obj-model 64x48x16: RMSE 8.6e-4)
+    on = gpu_render("obj-model", 64, 48, 16, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, bvh=pt.BVH_ON)
+    off = gpu_render("obj-model", 64, 48, 16, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, bvh=pt.BVH_OFF)
+    assert (on[2] == off[2]).mean() > 0.999
+    assert np.sqrt(((on[0].astype(np.float64) - off[0]) ** 2).mean()) <= 2 * 8.6e-4
 
 
 # The strict tests above run with the default cull mode, which is SAFE under strict math; the

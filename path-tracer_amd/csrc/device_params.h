@@ -104,3 +104,12 @@ int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s)
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
+// the same kernels compiled with the BVH traversal in place of the linear scans (PT_BVH 1)
+namespace ptk_fast_bvh {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+}
+namespace ptk_strict_bvh {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+}

@@ -2,6 +2,7 @@
 // approximations (PTGPU_MATH_FAST).  Compile with -ffp-contract=fast.
 #include "device_params.h"
 #define PT_STRICT 0
+#define PT_BVH 0
 #define PT_NS ptk_fast
 #include "radiance_device.inc"
 #include "radiance_kernels.inc"

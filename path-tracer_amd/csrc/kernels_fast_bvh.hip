@@ -1,0 +1,8 @@
+// kernels_fast_bvh.hip - the BVH variant (PTGPU_OPT_BVH) of kernels_fast.hip: the radiance kernels built with FMA contraction and f32 hardware
+// approximations (PTGPU_MATH_FAST).  Compile with -ffp-contract=fast.
+#include "device_params.h"
+#define PT_STRICT 0
+#define PT_BVH 1
+#define PT_NS ptk_fast_bvh
+#include "radiance_device.inc"
+#include "radiance_kernels.inc"

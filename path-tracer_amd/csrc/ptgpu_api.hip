@@ -496,10 +496,14 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
                        : (c->info.lights >= 2 && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
                                                                                     : PTGPU_KERNEL_MEGA);
     auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
-        if (kernel == PTGPU_KERNEL_MEGA)
-            return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);
-        return c->math == PTGPU_MATH_STRICT ? ptk_strict::launch_wavefront(p, cfg, s)
-                                            : ptk_fast::launch_wavefront(p, cfg, s);
+        const bool strict = c->math == PTGPU_MATH_STRICT;
+        if (p.n_bnodes) { // the BVH builds of the same kernels
+            if (kernel == PTGPU_KERNEL_MEGA)
+                return strict ? ptk_strict_bvh::launch_mega(p, cfg, s) : ptk_fast_bvh::launch_mega(p, cfg, s);
+            return strict ? ptk_strict_bvh::launch_wavefront(p, cfg, s) : ptk_fast_bvh::launch_wavefront(p, cfg, s);
+        }
+        if (kernel == PTGPU_KERNEL_MEGA) return strict ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);
+        return strict ? ptk_strict::launch_wavefront(p, cfg, s) : ptk_fast::launch_wavefront(p, cfg, s);
     };
 
     int launch_error = 0;

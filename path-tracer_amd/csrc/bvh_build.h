@@ -61,12 +61,18 @@ inline float bits_float(int v) {
 }
 
 // prims: 3 quads per primitive in index order (device_params.h); types[i]: PT_SPHERE / PT_TRIANGLE.
-inline Built build(const std::vector<float4> &prims, const std::vector<int> &types) {
+// keys (optional, with force_type): leaves never mix primitives of different keys and the leaf
+// order runs key by key (keys ascending, -1 last) - used to lay the hierarchy over the shadow
+// order, whose triangle groups are cluster-pure.  In that mode every primitive of the tree's type
+// is in the tree (a non-finite one gets an all-space box).
+inline Built build(const std::vector<float4> &prims, const std::vector<int> &types,
+                   const std::vector<int> *keys = nullptr, int force_type = -1) {
     Built out;
     const size_t n = types.size();
     size_t n_sph = 0;
     for (int t : types) n_sph += t == PT_SPHERE;
-    out.type = n_sph > n - n_sph ? PT_SPHERE : PT_TRIANGLE;
+    out.type = force_type >= 0 ? force_type : (n_sph > n - n_sph ? PT_SPHERE : PT_TRIANGLE);
+    auto key_of = [&](int i) { return keys ? ((*keys)[i] < 0 ? 0x7fffffff : (*keys)[i]) : 0; };
 
     std::vector<Box> boxes(n);
     std::vector<int> order;
@@ -93,10 +99,13 @@ inline Built build(const std::vector<float4> &prims, const std::vector<int> &typ
             b.lo[a] -= pad;
             b.hi[a] += pad;
         }
+        if (!finite && keys)
+            for (int a = 0; a < 3; ++a) { b.lo[a] = -3e38; b.hi[a] = 3e38; }
         boxes[i] = b;
-        if (types[i] == out.type && finite) order.push_back((int)i);
+        if (types[i] == out.type && (finite || keys)) order.push_back((int)i);
         else out.rest.push_back((int)i);
     }
+    if (keys) std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key_of(x) < key_of(y); });
 
     struct Task { int begin, end; };
     // recursive median-of-SAH-bins build over order[begin, end), emitting nodes in preorder
@@ -115,6 +124,17 @@ inline Built build(const std::vector<float4> &prims, const std::vector<int> &typ
         node_box.push_back(nb);
         leaf_first.push_back(-1);
         skip.push_back(0);
+        if (key_of(order[begin]) != key_of(order[end - 1])) { // split on the key boundary nearest the middle
+            int best_mid = -1;
+            for (int k = begin + 1; k < end; ++k)
+                if (key_of(order[k - 1]) != key_of(order[k]) &&
+                    (best_mid < 0 || std::abs(k - (begin + end) / 2) < std::abs(best_mid - (begin + end) / 2)))
+                    best_mid = k;
+            rec(begin, best_mid);
+            rec(best_mid, end);
+            skip[me] = (int)node_box.size();
+            return;
+        }
         if (end - begin <= kLeaf) {
             leaf_first[me] = (int)out.prim_of_slot.size();
             for (int k = 0; k < kLeaf; ++k) out.prim_of_slot.push_back(k < end - begin ? order[begin + k] : -1);
@@ -155,9 +175,15 @@ inline Built build(const std::vector<float4> &prims, const std::vector<int> &typ
                 mid = (int)(it - order.begin());
             }
         }
-        if (mid <= begin || mid >= end) { // all centroids equal: split by count
-            std::stable_sort(order.begin() + begin, order.begin() + end, [&](int x, int y) { return centre(x) < centre(y); });
-            mid = (begin + end) / 2;
+        // Order the range along the axis and move the split to a whole number of leaves on the left,
+        // so that at most one leaf per subtree is partly filled (a filler slot costs a full test).
+        std::stable_sort(order.begin() + begin, order.begin() + end, [&](int x, int y) { return centre(x) < centre(y); });
+        if (mid <= begin || mid >= end) mid = (begin + end) / 2; // all centroids equal: split by count
+        {
+            int left = ((mid - begin + kLeaf / 2) / kLeaf) * kLeaf;
+            if (left <= 0) left = kLeaf;
+            if (left >= end - begin) left = ((end - begin - 1) / kLeaf) * kLeaf;
+            mid = begin + left;
         }
         rec(begin, mid);
         rec(mid, end);

@@ -86,6 +86,10 @@ struct PtDeviceParams {
     const float4 *bvh;
     const int *bvh_ids, *bvh_rest_ids;
     int n_bnodes, n_bslots, n_brest, bvh_type;
+    // hybrid (fast build with candidate sets): a hierarchy whose leaves are the triangle groups of
+    // sprims (leaf `first` = slot within the triangle section); n_hnodes == 0 switches it off
+    const float4 *hyb_nodes;
+    int n_hnodes;
 };
 
 struct PtLaunchConfig {
@@ -106,6 +110,10 @@ int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
 // the same kernels compiled with the BVH traversal in place of the linear scans (PT_BVH 1)
 namespace ptk_fast_bvh {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+}
+namespace ptk_fast_hyb { // PT_BVH 2: extension rays through the hierarchy over the shadow order
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }

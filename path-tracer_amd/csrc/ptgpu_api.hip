@@ -79,6 +79,9 @@ struct ptgpu_ctx {
     int *d_bvh_ids_index = nullptr, *d_bvh_ids_slot = nullptr, *d_bvh_rest_index = nullptr, *d_bvh_rest_slot = nullptr;
     int n_bnodes = 0, n_bslots = 0, n_brest = 0, bvh_type = 0;
     bool bvh_auto = false;             // AUTO turns it on for this scene
+    float4 *d_hyb_nodes = nullptr;     // hierarchy over the shadow order (hybrid)
+    int n_hnodes = 0;
+    uint32_t lds_fast_hyb = 0;
     uint32_t lds_bvh = 0;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
@@ -121,6 +124,9 @@ void free_scene(ptgpu_ctx *c) {
     }
     c->d_bvh = nullptr;
     c->n_bnodes = c->n_bslots = c->n_brest = 0;
+    if (c->d_hyb_nodes) (void)hipFree(c->d_hyb_nodes);
+    c->d_hyb_nodes = nullptr;
+    c->n_hnodes = 0;
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     c->d_sprims = nullptr;
@@ -211,6 +217,9 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
         p.n_bslots = c->n_bslots;
         p.n_brest = c->n_brest;
         p.bvh_type = c->bvh_type;
+    } else if (c->bvh != PTGPU_BVH_OFF && c->math == PTGPU_MATH_FAST && p.smask && c->n_hnodes > 0) {
+        p.hyb_nodes = c->d_hyb_nodes; // candidate sets stay on; extension rays take the hierarchy
+        p.n_hnodes = c->n_hnodes;
     }
     return p;
 }
@@ -223,6 +232,7 @@ struct ShadowTables {
     std::vector<float4> cluster_bounds;              // (centre, padded radius) per cluster
     std::vector<unsigned long long> cluster_masks;   // (1 + clusters) x mw_tri words
     std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
+    std::vector<float4> hyb_nodes;                   // hierarchy whose leaves are the triangle groups
     std::vector<unsigned long long> safe, tight;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
     double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
@@ -366,15 +376,17 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     for (size_t i = 0; i < types.size(); ++i)
         if (types[i] == PT_SPHERE) sph_slots.push_back((int)i);
     pad(sph_slots, kSphereGroup);
-    std::vector<std::pair<int, int>> cluster_groups(n_clusters); // [first group, end group) in triangle groups
-    for (int c = 0; c <= n_clusters; ++c) {
-        const int want = c < n_clusters ? c : -1;
-        const int begin = (int)tri_slots.size() / kTriGroup;
-        for (size_t i = 0; i < types.size(); ++i)
-            if (types[i] == PT_TRIANGLE && t.cluster_of[i] == want) tri_slots.push_back((int)i);
-        pad(tri_slots, kTriGroup);
-        if (c < n_clusters) cluster_groups[c] = {begin, (int)tri_slots.size() / kTriGroup};
-    }
+    // Triangle order = leaf order of a hierarchy whose leaves never mix clusters (bvh_build.h,
+    // keyed build): the groups of 4 below are its leaves, cluster by cluster, unclustered last.
+    static_assert(kTriGroup == ptbvh::kLeaf, "a shadow group is a leaf");
+    const ptbvh::Built over = ptbvh::build(prims, types, &t.cluster_of, PT_TRIANGLE);
+    tri_slots = over.prim_of_slot;
+    t.hyb_nodes = over.nodes;
+    auto cluster_of_group = [&](int g) {
+        for (int k = 0; k < kTriGroup; ++k)
+            if (tri_slots[g * kTriGroup + k] >= 0) return t.cluster_of[tri_slots[g * kTriGroup + k]];
+        return -1;
+    };
     t.sg_sph = (int)sph_slots.size() / kSphereGroup;
     t.sg_tri = (int)tri_slots.size() / kTriGroup;
     t.mw_sph = (t.sg_sph + 63) / 64;
@@ -399,12 +411,8 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
 
     // cluster_masks: row 0 = triangle groups outside every cluster, row 1 + c = groups of cluster c
     t.cluster_masks.assign((size_t)(n_clusters + 1) * t.mw_tri, 0ull);
-    for (int g = 0; g < t.sg_tri; ++g) {
-        int row = 0;
-        for (int c = 0; c < n_clusters; ++c)
-            if (g >= cluster_groups[c].first && g < cluster_groups[c].second) row = 1 + c;
-        t.cluster_masks[(size_t)row * t.mw_tri + g / 64] |= 1ull << (g % 64);
-    }
+    for (int g = 0; g < t.sg_tri; ++g)
+        t.cluster_masks[(size_t)(1 + cluster_of_group(g)) * t.mw_tri + g / 64] |= 1ull << (g % 64);
 
     const size_t n_lights = lights.size() / 4, n_prims = types.size();
     const int words = t.mw_sph + t.mw_tri;
@@ -475,6 +483,7 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     PtLaunchConfig cfg{};
     PtDeviceParams probe = make_params(c, first_sample, 1);
     const uint32_t stage_bytes = probe.n_bnodes            ? c->lds_bvh
+                                 : probe.n_hnodes           ? c->lds_fast_hyb
                                  : c->math == PTGPU_MATH_FAST ? c->lds_fast
                                  : probe.smask               ? c->lds_strict_cull
                                                              : c->lds_strict;
@@ -502,6 +511,8 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
                 return strict ? ptk_strict_bvh::launch_mega(p, cfg, s) : ptk_fast_bvh::launch_mega(p, cfg, s);
             return strict ? ptk_strict_bvh::launch_wavefront(p, cfg, s) : ptk_fast_bvh::launch_wavefront(p, cfg, s);
         }
+        if (p.n_hnodes)
+            return kernel == PTGPU_KERNEL_MEGA ? ptk_fast_hyb::launch_mega(p, cfg, s) : ptk_fast_hyb::launch_wavefront(p, cfg, s);
         if (kernel == PTGPU_KERNEL_MEGA) return strict ? ptk_strict::launch_mega(p, cfg, s) : ptk_fast::launch_mega(p, cfg, s);
         return strict ? ptk_strict::launch_wavefront(p, cfg, s) : ptk_fast::launch_wavefront(p, cfg, s);
     };
@@ -730,6 +741,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     const uint32_t lds_strict = fits(prims.size() * sizeof(float4) + light_bytes);
     const uint32_t lds_strict_cull = fits(prims.size() * sizeof(float4) + light_bytes + shadow_bytes);
     const uint32_t lds_fast = fits(shadow_bytes + light_bytes + st.cluster_bounds.size() * sizeof(float4));
+    const uint32_t lds_fast_hyb = fits(shadow_bytes + light_bytes + (st.cluster_bounds.size() + st.hyb_nodes.size()) * sizeof(float4));
     info.lds_bytes = lds_fast;
 
     // BVH: built for every scene with something to gain; AUTO uses it when the candidate sets do
@@ -796,6 +808,11 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         ctx->bvh_type = bvh.type;
     }
     ctx->bvh_auto = !use_tables && in_tree >= 64 && bvh.rest.size() <= 64;
+    if (use_tables && st.hyb_nodes.size() / 2 >= 8 && info.triangles >= 32) {
+        HIP_TRY(upload(ctx->d_hyb_nodes, st.hyb_nodes));
+        ctx->n_hnodes = (int)(st.hyb_nodes.size() / 2);
+    }
+    ctx->lds_fast_hyb = lds_fast_hyb;
     ctx->lds_bvh = lds_bvh;
     ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
     info.clusters = (uint32_t)ctx->n_clusters;

@@ -100,6 +100,18 @@ def test_bvh_full_size_equals_linear_scan(name, lds):
     assert same_bits(off[0], on[0]) and (off[1] == on[1]).all() and (off[2] == on[2]).all()
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+@pytest.mark.parametrize("lds", [1, 0])
+def test_hybrid_extension_hierarchy_is_bit_identical_in_the_fast_build(kernel, lds):
+    # Fast build with candidate sets: extension rays walk the hierarchy laid over the shadow order
+    # (BVH AUTO) or scan it linearly (BVH OFF).  Same tests per visited primitive, same tie rule:
+    # the two images must be the same bits.
+    for name, w, h, spp in (("cornell", 160, 120, 6), ("materials", 160, 120, 12)):
+        a = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_FAST, lds=lds, bvh=pt.BVH_AUTO)
+        b = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_FAST, lds=lds, bvh=pt.BVH_OFF)
+        assert same_bits(a[0], b[0]) and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+
+
 def test_bvh_auto_choice_and_fast_build():
     g = pt.Gpu(0, 0)
     for name, expect_tree in (("obj-model", 322), ("large-object", 968), ("complex", 783)):

@@ -1,0 +1,144 @@
+"""Synthetic scenes that push the shadow-ray tables and the hierarchies past what the reference's scene
+files reach: several mask words per light, more than 8 mesh clusters, duplicated geometry (exact
+distance ties), degenerate and non-finite primitives.  Bars as in test_gpu_parity.py: the strict
+build is bit-exact against the CPU oracle in every mode; the fast build's modes agree with each other.
+"""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+import pyptgpu as pt
+from conftest import same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def icosphere(center, radius, subdiv):
+    t = (1 + 5 ** 0.5) / 2
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10),
+         (8, 6, 7), (9, 8, 1)]
+    v = [np.array(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        nf, cache = [], {}
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    v = np.array(v) * radius + np.array(center)
+    return np.array([[v[a], v[b], v[c]] for a, b, c in f], dtype=np.float32)
+
+
+def triangles(tris, emission=(0, 0, 0), color=(.7, .7, .7), material=0):
+    o = np.zeros(len(tris), dtype=pt.OBJECT_DTYPE)
+    o["type"] = 1
+    o["material_id"] = material
+    o["emission"] = emission
+    o["color"] = color
+    o["p1"], o["p2"], o["p3"] = tris[:, 0], tris[:, 1], tris[:, 2]
+    e1, e2 = tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]
+    o["area"] = (0.5 * np.linalg.norm(np.cross(e1, e2), axis=1)).astype(np.float32)   # as readScene computes it
+    return o
+
+
+def sphere(radius, center, emission=(0, 0, 0), color=(.75, .75, .75), material=0):
+    o = np.zeros(1, dtype=pt.OBJECT_DTYPE)
+    o["type"], o["material_id"], o["radius"], o["center"] = 0, material, radius, center
+    o["emission"], o["color"] = emission, color
+    o["area"] = 4 * np.pi * radius * radius
+    return o
+
+
+def make_scene(objects, w, h):
+    sc = pt.LoadedScene("cornell", w, h)      # camera, materials, gamma, sky of a real scene; objects replaced
+    sc.objects = np.ascontiguousarray(np.concatenate(objects))
+    sc.object_count = len(sc.objects)
+    em = sc.objects["emission"]
+    sc.light_count = int((~((em[:, 0] == 0) & (em[:, 2] == 0))).sum())
+    return sc
+
+
+def room():
+    return [sphere(1e4, (1e4 - 54, 40.8, 81.6), color=(.75, .25, .25)), sphere(1e4, (-1e4 + 56, 40.8, 81.6), color=(.25, .25, .75)),
+            sphere(1e4, (0, 40.8, 1e4)), sphere(1e4, (0, 40.8, -1e4 + 270), color=(0, 0, 0)),
+            sphere(1e4, (0, 1e4, 81.6)), sphere(1e4, (0, -1e4 + 81.6, 81.6))]
+
+
+def big_scene():
+    """A 320-triangle emissive ball, twelve 80-triangle balls (more than 8 clusters), one 1280-triangle
+    ball: 2 560 triangles, 320 lights, 11 mask words per light."""
+    rng = np.random.default_rng(7)
+    objs = room()
+    objs.append(triangles(icosphere((-20, 30, 60), 9, 2), emission=(6, 6, 6)))
+    for _ in range(12):
+        objs.append(triangles(icosphere(rng.uniform((-40, 5, 30), (40, 60, 120)), rng.uniform(3, 7), 1),
+                              color=rng.uniform(.3, .9, 3)))
+    objs.append(triangles(icosphere((25, 15, 70), 14, 3), color=(.9, .9, .9), material=1))   # a mirror ball
+    return objs
+
+
+def render(sc, w, h, spp, **kw):
+    g = pt.Gpu(0, 0, **kw)
+    g.set_scene(sc)
+    info = g.scene_info()
+    g.resize(w, h, pt.seed_block(w, h))
+    g.render(spp)
+    out = (g.colors(), g.pixels(), g.seeds(), info)
+    g.close()
+    return out
+
+
+def test_many_mask_words_and_clusters_strict_modes_equal_the_oracle():
+    w, h, spp = 48, 36, 1
+    sc = make_scene(big_scene(), w, h)
+    cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    for kw in (dict(shadow_cull=pt.CULL_OFF, bvh=pt.BVH_OFF), dict(shadow_cull=pt.CULL_SAFE, bvh=pt.BVH_OFF),
+               dict(bvh=pt.BVH_ON), dict(shadow_cull=pt.CULL_SAFE, bvh=pt.BVH_OFF, lds=0),
+               dict(shadow_cull=pt.CULL_SAFE, bvh=pt.BVH_OFF, kernel=pt.KERNEL_MEGA)):
+        colors, pixels, seeds, info = render(sc, w, h, spp, math=pt.MATH_STRICT, **kw)
+        assert info["triangles"] == 2560 and info["lights"] == 320 and info["clusters"] == 8
+        assert info["shadow_tests_safe"] < 0.9 * info["primitives"]
+        assert (seeds == cpu.seeds).all(), kw
+        assert same_bits(colors, cpu.colors), kw
+        assert (pixels == cpu.pixels).all(), kw
+
+
+def test_many_mask_words_and_clusters_fast_modes_agree():
+    w, h, spp = 96, 72, 4
+    sc = make_scene(big_scene(), w, h)
+    base = render(sc, w, h, spp, math=pt.MATH_FAST, kernel=pt.KERNEL_WAVEFRONT, ray_bins=0, bvh=pt.BVH_OFF)
+    for kw in (dict(ray_bins=1, bvh=pt.BVH_OFF), dict(ray_bins=1, bvh=pt.BVH_AUTO), dict(ray_bins=0, bvh=pt.BVH_AUTO),
+               dict(ray_bins=1, bvh=pt.BVH_AUTO, lds=0), dict(bvh=pt.BVH_ON)):
+        got = render(sc, w, h, spp, math=pt.MATH_FAST, kernel=pt.KERNEL_WAVEFRONT, **kw)
+        assert (got[2] == base[2]).all(), kw
+        ok = ~np.isnan(base[0]).any(1) & ~np.isnan(got[0]).any(1)
+        rel = np.abs(got[0][ok] - base[0][ok]).max(1) / np.maximum(np.abs(base[0][ok]).max(1), 1e-3)
+        assert (rel > 1e-4).mean() < 0.01, (kw, (rel > 1e-4).mean())   # TIGHT sets vs hierarchy: grazing rays only
+
+
+def test_duplicated_and_degenerate_geometry_keeps_the_tie_rule():
+    # every triangle of a ball twice (second copy with another colour: the FIRST must win every tie),
+    # plus zero-area and NaN triangles and a NaN sphere, which never hit
+    w, h, spp = 64, 48, 2
+    ball = icosphere((0, 30, 80), 20, 2)
+    junk = np.array([[[1, 1, 1], [1, 1, 1], [1, 1, 1]], [[np.nan, 0, 0], [1, 0, 0], [0, 1, 0]],
+                     [[0, 0, 0], [1, 0, 0], [2, 0, 0]]], dtype=np.float32)
+    objs = room() + [triangles(ball, color=(.9, .1, .1)), triangles(ball, color=(.1, .9, .1)), triangles(junk),
+                     sphere(np.float32(np.nan), (0, 40, 80)), sphere(5, (0, 70, 80), emission=(12, 12, 12))]
+    sc = make_scene(objs, w, h)
+    cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    red, green = cpu.colors[:, 0].sum(), cpu.colors[:, 1].sum()
+    assert red > green                                    # the first (red) copy is the one that is seen
+    for kw in (dict(bvh=pt.BVH_OFF), dict(bvh=pt.BVH_ON), dict(bvh=pt.BVH_ON, kernel=pt.KERNEL_MEGA, lds=0)):
+        colors, pixels, seeds, _ = render(sc, w, h, spp, math=pt.MATH_STRICT, **kw)
+        assert (seeds == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all(), kw

@@ -196,6 +196,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.sprims = c->d_sprims;
     p.sshade = c->d_sshade;
     p.smask = cull == PTGPU_CULL_SAFE ? c->d_smask_safe : cull == PTGPU_CULL_TIGHT ? c->d_smask_tight : nullptr;
+    p.n_sph_real = (int)c->info.spheres;
     p.sg_sph = c->sg_sph;
     p.sg_tri = c->sg_tri;
     p.mw_sph = c->mw_sph;

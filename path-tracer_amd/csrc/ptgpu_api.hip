@@ -235,6 +235,7 @@ struct ShadowTables {
     std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
     std::vector<float4> hyb_nodes;                   // hierarchy whose leaves are the triangle groups
     std::vector<unsigned long long> safe, tight;
+    bool tables_built = false;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
     double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
 };
@@ -433,6 +434,15 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         }
         mean = n_lights ? total / n_lights : 0;
     };
+    // lights x primitives decisions: beyond 2^26 of them (or 8 MiB of masks) the tables are not built
+    // and every shadow ray scans everything, as upstream
+    t.tables_built = (double)n_lights * (double)n_prims <= (double)(1u << 26) &&
+                     (double)n_lights * words * sizeof(unsigned long long) <= (double)(8u << 20);
+    if (!t.tables_built) {
+        t.mean_safe = t.mean_tight = (double)n_prims;
+        t.light_clusters.assign(n_lights, 0u);
+        return;
+    }
     masks(PTGPU_CULL_SAFE, t.safe, t.mean_safe);
     masks(PTGPU_CULL_TIGHT, t.tight, t.mean_tight);
 
@@ -732,8 +742,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     std::vector<float4> sshade;
     for (int slot : st.prim_of_slot)
         for (int q = 0; q < 4; ++q) sshade.push_back(slot >= 0 ? shade[4 * slot + q] : make_float4(0.f, 0.f, 0.f, 0.f));
-    const size_t mask_bytes = st.tight.size() * sizeof(unsigned long long);
-    const bool use_tables = info.lights > 0 && st.mean_tight <= 0.9 * info.primitives && mask_bytes <= (8u << 20);
+    const bool use_tables = st.tables_built && info.lights > 0 && st.mean_tight <= 0.9 * info.primitives;
     info.shadow_groups = (uint32_t)(st.sg_sph + st.sg_tri);
     info.shadow_tests_safe = use_tables ? (float)st.mean_safe : (float)info.primitives;
     info.shadow_tests_tight = use_tables ? (float)st.mean_tight : (float)info.primitives;
@@ -840,6 +849,10 @@ int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uin
     pack_geometry(objects, object_count, light_count, geo);
     *n_lights = (uint32_t)(geo.lights.size() / 4);
     if (!keep) return PTGPU_OK;
+    if ((double)*n_lights * (double)geo.types.size() > (double)(1u << 26))
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: %u lights x %zu primitives is beyond the size the "
+                                        "tables are built for (set_scene scans everything for such a scene)",
+                    *n_lights, geo.types.size());
     const std::vector<uint8_t> by_prim = shadow_candidates(geo.prims, geo.types, geo.lights, mode);
     const size_t n_prims = geo.types.size();
     memset(keep, 0, (size_t)*n_lights * object_count);

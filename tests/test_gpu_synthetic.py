@@ -142,3 +142,23 @@ def test_duplicated_and_degenerate_geometry_keeps_the_tie_rule():
     for kw in (dict(bvh=pt.BVH_OFF), dict(bvh=pt.BVH_ON), dict(bvh=pt.BVH_ON, kernel=pt.KERNEL_MEGA, lds=0)):
         colors, pixels, seeds, _ = render(sc, w, h, spp, math=pt.MATH_STRICT, **kw)
         assert (seeds == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all(), kw
+
+
+def test_scene_too_large_for_the_tables_falls_back_to_the_hierarchy():
+    # 20 480 emissive triangles: lights x primitives = 4e8 decisions, beyond what set_scene builds
+    # tables for; it must neither blow up nor change results: the BVH (AUTO) carries the scene.
+    w, h = 8, 8
+    sc = make_scene(room() + [triangles(icosphere((0, 40, 80), 15, 5), emission=(1, 1, 1))], w, h)
+    assert sc.light_count == 20480
+    with pytest.raises(pt.GpuError):
+        pt.shadow_candidates(sc, pt.CULL_SAFE)
+    cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 1).pass_oracle(1, threads=8)
+    g = pt.Gpu(0, pt.INTEGRATOR_DL, math=pt.MATH_STRICT)
+    g.set_scene(sc)
+    info = g.scene_info()
+    assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 20486
+    assert info["bvh_primitives"] == 20480
+    g.resize(w, h, pt.seed_block(w, h))
+    g.render(1)
+    assert (g.seeds() == cpu.seeds).all() and same_bits(g.colors(), cpu.colors)
+    g.close()

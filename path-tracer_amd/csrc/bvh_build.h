@@ -92,6 +92,10 @@ inline Built build(const std::vector<float4> &prims, const std::vector<int> &typ
                                     {(double)a.x + e2.x, (double)a.y + e2.y, (double)a.z + e2.z}};
             for (auto &p : v) b.grow(p);
         }
+        for (int q = 0; q < 3; ++q) { // min/max drop a NaN, so look at the record itself
+            const float4 v = prims[3 * i + q];
+            finite = finite && std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z) && (q > 0 || std::isfinite(v.w));
+        }
         for (int a = 0; a < 3; ++a) finite = finite && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
         // pad far beyond the rounding of the primitive tests: 1e-4 of the extent and position + 10 EPSILON
         for (int a = 0; a < 3; ++a) {

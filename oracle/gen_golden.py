@@ -33,6 +33,7 @@ CASES = [  # scene, W, H, spp, integrator
     ("complex", 32, 24, 2, 0), ("table-and-mirror", 24, 16, 2, 0), ("stacked-spheres", 32, 24, 2, 0),
     ("simple", 37, 19, 3, 0),          # ragged: not a multiple of the 8x8 wave tile
     ("cornell-original", 32, 24, 4, 0),
+    ("obj-model-bunny", 32, 24, 2, 0), ("obj-model-bunny", 32, 24, 2, 1),   # 5 050 triangles (data/scenes)
 ]
 
 

@@ -91,7 +91,7 @@ def test_bvh_strict_is_bit_exact_against_reference_golden(fn, kernel):
 
 
 @pytest.mark.parametrize("lds", [1, 0])
-@pytest.mark.parametrize("name", ["obj-model", "large-object", "complex", "table-and-mirror", "cornell"])
+@pytest.mark.parametrize("name", ["obj-model", "large-object", "complex", "table-and-mirror", "cornell", "obj-model-bunny"])
 def test_bvh_full_size_equals_linear_scan(name, lds):
     # 1024x768: ~10^7 extension rays and as many shadow rays per pass through the hierarchy
     w, h, spp = 1024, 768, 2

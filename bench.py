@@ -104,14 +104,9 @@ def main():
         raise SystemExit("bench.py needs a GPU: the radiance path has no CPU fallback")
     local_rank %= torch.cuda.device_count()  # rehearsals may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-
+    # The library's four region streams are created BEFORE the process group: HIP spreads streams
+    # over GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and with RCCL's streams in
+    # first the regions double up on a queue and a pass runs as slowly as with one stream (+14 %).
     w, h = args.width, args.height
     sc = pt.LoadedScene(args.scene, w, h)
     seeds = pt.seed_block(w, h, rank)
@@ -123,6 +118,13 @@ def main():
     cull = args.cull if args.cull != "auto" else ("tight" if args.math == "fast" else "safe")
     g.set_scene(sc)
     g.resize(w, h, seeds)
+    dist = None
+    if world > 1 or "RANK" in os.environ:   # under torchrun even a group of one goes through RCCL (rehearsal on a 1-GPU box)
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * w * h),
                                device=torch.device("cuda", local_rank))
 
@@ -134,17 +136,32 @@ def main():
 
     for _ in range(args.warmup):
         g.render_timed(args.passes)
+    if dist is not None:
+        # RCCL sets up channels and loads its kernels on the first collective of a given size: that
+        # belongs to start-up, not to the timed region
+        g.finish()
+        warm = torch.zeros_like(colors_t)
+        for _ in range(max(1, min(args.warmup, 2))):
+            dist.all_reduce(warm, op=dist.ReduceOp.SUM)
+        del warm
     barrier()
     launch_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         launch_ms.append(g.render_timed(args.passes))  # HIP events on the library's stream
     g.finish()
+    t1 = time.perf_counter()
     scale = multigpu.allreduce_mean_(colors_t, world)  # the one collective of the path
     torch.cuda.synchronize()
+    t2 = time.perf_counter()
     g.scale_and_repack(scale)
+    g.finish()
+    t3 = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("PT_BENCH_TRACE"):
+        print(f"[rank {rank}] render {1e3 * (t1 - t0):.2f} ms, all-reduce {1e3 * (t2 - t1):.2f}, repack {1e3 * (t3 - t2):.2f}, "
+              f"barrier {1e3 * (t0 + elapsed - t3):.2f}", file=sys.stderr, flush=True)
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

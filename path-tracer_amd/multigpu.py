@@ -30,7 +30,7 @@ class DeviceArray:
 def allreduce_mean_(colors_tensor, world):
     """In-place: colors <- sum over ranks; returns the scale (1/world) still to be applied."""
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):   # a group of one still goes through RCCL
         dist.all_reduce(colors_tensor, op=dist.ReduceOp.SUM)
     return 1.0 / world
 

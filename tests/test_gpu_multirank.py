@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, backend="gloo"):
     sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
     import torch
     import torch.distributed as dist
@@ -32,7 +32,10 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     sc = pt.LoadedScene("cornell-large", W, H)
     g = pt.Gpu(0, 0, math=pt.MATH_STRICT)
     g.set_scene(sc)
@@ -71,3 +74,16 @@ def test_two_ranks_one_gpu(tmp_path):
         v = pt.Vec3(*[float(x) for x in c[i]])
         z = pt.Vec3(0, 0, 0)
         assert ob.oracle().oracle_accumulate(C.byref(z), C.byref(v), 0, sc.scene.gamma) == pix[0][i]
+
+
+def test_rccl_group_of_one(tmp_path):
+    # the box has one GPU, so RCCL can only be rehearsed with a group of one: the same calls as N > 1
+    # (communicator on the device, in-place all-reduce of the aliased colour buffer, repack)
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import oracle_binding as ob
+    import pyptgpu as pt
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "nccl"), nprocs=1, join=True)
+    got = np.load(tmp_path / "colors0.npy")
+    sc = pt.LoadedScene("cornell-large", W, H)
+    want = ob.Render(sc, pt.seed_block(W, H, 0), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(PASSES).colors
+    assert got.tobytes() == want.tobytes()

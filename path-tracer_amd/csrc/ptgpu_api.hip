@@ -71,7 +71,7 @@ struct ptgpu_ctx {
     float4 *d_prims = nullptr, *d_shade = nullptr, *d_lights = nullptr;
     int4 *d_segs = nullptr;
     // shadow-ray tables (device_params.h); null when the scene gains nothing from them
-    float4 *d_sprims = nullptr, *d_sshade = nullptr;
+    float4 *d_sprims = nullptr, *d_sprims_planes = nullptr, *d_sshade = nullptr;
     unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_cmask = nullptr;
     float4 *d_cbounds = nullptr;
     // BVH (device_params.h): one block + the id tables in each build's numbering
@@ -111,6 +111,7 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_segs) (void)hipFree(c->d_segs);
     if (c->d_sprims) (void)hipFree(c->d_sprims);
+    if (c->d_sprims_planes) (void)hipFree(c->d_sprims_planes);
     if (c->d_sshade) (void)hipFree(c->d_sshade);
     c->d_sshade = nullptr;
     if (c->d_cmask) (void)hipFree(c->d_cmask);
@@ -130,6 +131,7 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     c->d_sprims = nullptr;
+    c->d_sprims_planes = nullptr;
     c->d_smask_safe = c->d_smask_tight = nullptr;
     c->d_prims = c->d_shade = c->d_lights = nullptr;
     c->d_segs = nullptr;
@@ -207,6 +209,8 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.cmask = c->d_cmask;
     p.cbounds = c->d_cbounds;
     const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
+    // the fast build's own translation units read triangles in plane form (radiance_device.inc)
+    if (c->math == PTGPU_MATH_FAST && !use_bvh) p.sprims = c->d_sprims_planes;
     if (use_bvh) { // the hierarchy replaces the candidate sets
         p.smask = nullptr;
         p.n_clusters = 0;
@@ -228,6 +232,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
 // ---- shadow-ray candidate sets (PTGPU_OPT_SHADOW_CULL, ptgpu.h) ---------------------------------
 struct ShadowTables {
     std::vector<float4> sprims;
+    std::vector<float4> sprims_planes; // the same array with the triangles in plane form (fast build)
     std::vector<int> prim_of_slot;   // shadow-order slot -> primitive index, -1 for a filler
     std::vector<int> cluster_of;     // primitive -> triangle cluster or -1
     std::vector<float4> cluster_bounds;              // (centre, padded radius) per cluster
@@ -410,6 +415,22 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     };
     put(sph_slots, true);
     put(tri_slots, false);
+    // plane form of the triangles (radiance_device.inc, triangle_planes_t), derived in double; a
+    // triangle without area or with a non-finite coordinate becomes the never-hit filler
+    t.sprims_planes = t.sprims;
+    for (size_t slot = sph_slots.size(); slot < t.prim_of_slot.size(); ++slot) {
+        float4 *q = &t.sprims_planes[3 * slot];
+        const D3 p1 = d3(q[0]), e1 = d3(q[1]), e2 = d3(q[2]);
+        const D3 n = cross(e1, e2);
+        const double nn = dot(n, n);
+        q[0] = q[1] = q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(nn > 0.0) || !std::isfinite(nn) || !std::isfinite(dot(p1, p1))) continue;
+        const D3 c1 = cross(e2, n), c2 = cross(n, e1);
+        const D3 n1 = {c1.x / nn, c1.y / nn, c1.z / nn}, n2 = {c2.x / nn, c2.y / nn, c2.z / nn};
+        q[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)dot(n, p1));
+        q[1] = make_float4((float)n1.x, (float)n1.y, (float)n1.z, (float)-dot(n1, p1));
+        q[2] = make_float4((float)n2.x, (float)n2.y, (float)n2.z, (float)-dot(n2, p1));
+    }
 
     // cluster_masks: row 0 = triangle groups outside every cluster, row 1 + c = groups of cluster c
     t.cluster_masks.assign((size_t)(n_clusters + 1) * t.mw_tri, 0ull);
@@ -799,6 +820,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     HIP_TRY(upload(ctx->d_lights, dlights));
     HIP_TRY(upload(ctx->d_segs, segs));
     HIP_TRY(upload(ctx->d_sprims, st.sprims));
+    HIP_TRY(upload(ctx->d_sprims_planes, st.sprims_planes));
     HIP_TRY(upload(ctx->d_sshade, sshade));
     if (use_tables) {
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));

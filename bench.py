@@ -83,8 +83,8 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
-    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "auto"],
-                    help="shadow-ray candidate sets (auto = tight with fast math, safe with strict)")
+    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "auto"],
+                    help="shadow-ray candidate sets (auto = enclosed with fast math, safe with strict)")
     ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4)")
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
@@ -114,8 +114,9 @@ def main():
                kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
                math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT, streams=args.streams,
                passes_per_launch=args.passes_per_launch,
-               shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "auto": pt.CULL_AUTO}[args.cull])
-    cull = args.cull if args.cull != "auto" else ("tight" if args.math == "fast" else "safe")
+               shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
+                            "auto": pt.CULL_AUTO}[args.cull])
+    cull = args.cull if args.cull != "auto" else ("enclosed" if args.math == "fast" else "safe")
     g.set_scene(sc)
     g.resize(w, h, seeds)
     dist = None
@@ -176,7 +177,7 @@ def main():
         baseline, flops_per_path, ref_flops_per_path, counters = (None, None, None, None)
         if world == 1 and not args.no_cpu:
             baseline, flops_per_path, ref_flops_per_path, counters = cpu_baseline(
-                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT}[cull])
+                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED}[cull])
         # One step = args.passes passes.  With S region streams a pass is S concurrent launches of
         # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the
         # library's stream (fork/join), so the per-launch figure below is step time / sequential

@@ -83,9 +83,17 @@ enum {
  *   TIGHT also culls primitives that touch the plane from behind (closed half-space, tolerance
  *         1e-5 relative): exact in real arithmetic; in floating point a ray grazing the light's
  *         plane within rounding distance may see a different occluder than upstream.
- *   AUTO  = SAFE under PTGPU_MATH_STRICT, TIGHT under PTGPU_MATH_FAST. */
+ *   ENCLOSED  TIGHT, and a sphere that is not a dielectric leaves the set of every triangle light
+ *         that lies wholly inside it (the r = 1e4 wall spheres of the upstream scenes): a segment
+ *         between two points of a ball stays in the ball, and a path that starts inside such a
+ *         sphere never leaves it (it is opaque), so in real arithmetic the sphere cannot occlude.
+ *         Upstream's float discriminant can still report the sphere a ray starts on ("acne":
+ *         1e-4 of cornell.txt's radiance, scripts/wall_sphere_shadow.py) - rounding-level, like
+ *         TIGHT's grazing rays.  The library checks at every launch that the camera is inside
+ *         every sphere this rule dropped, and renders with the TIGHT sets when it is not.
+ *   AUTO  = SAFE under PTGPU_MATH_STRICT, ENCLOSED under PTGPU_MATH_FAST. */
 enum {
-    PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3
+    PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3, PTGPU_CULL_ENCLOSED = 4
 };
 enum {
     PTGPU_MATH_FAST   = 0, /* FMA contraction on, v_rcp/v_rsq/v_sqrt/v_sin/v_cos f32 approximations:
@@ -172,6 +180,7 @@ typedef struct ptgpu_scene_info {
     uint32_t shadow_groups;        /* primitive groups in the shadow-ray ordering (0 = no cull tables) */
     float    shadow_tests_safe;    /* mean primitives tested per shadow ray under SAFE, light-averaged */
     float    shadow_tests_tight;   /* same under TIGHT; equals `primitives` padded when nothing is culled */
+    float    shadow_tests_enclosed; /* same under ENCLOSED */
     uint32_t clusters;             /* triangle clusters the fast build bins shadow rays on (0..8) */
     uint32_t clustered_triangles;  /* triangles inside them */
     uint32_t bvh_nodes;            /* nodes of the hierarchy built for PTGPU_OPT_BVH (0 = none) */
@@ -181,7 +190,8 @@ int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 
 /* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
  * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
- * ptgpu_set_scene would stage from the same arguments and mode SAFE or TIGHT (OFF: all ones),
+ * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT or ENCLOSED (OFF: all
+ * ones; ENCLOSED as if the camera were inside every sphere the rule drops),
  * keep[l * object_count + i] = 1 when object i is scanned for a shadow ray towards the l-th light
  * (sampling order), 0 when it is culled or is not a sphere/triangle.  *n_lights receives the number
  * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the

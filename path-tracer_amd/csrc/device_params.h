@@ -48,7 +48,7 @@
 #include <stdint.h>
 
 constexpr int kLightQuads = 5;
-constexpr int kSphereGroup = 6, kTriGroup = 4; // primitives per shadow group, tested back to back with no exit check
+constexpr int kSphereGroup = 1, kTriGroup = 4; // primitives per shadow group, tested back to back with no exit check
                                                // in between (6: the wall spheres of a room are one group; measured 2: -3.7 %)
 
 struct PtDeviceParams {

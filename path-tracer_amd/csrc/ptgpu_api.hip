@@ -72,7 +72,8 @@ struct ptgpu_ctx {
     int4 *d_segs = nullptr;
     // shadow-ray tables (device_params.h); null when the scene gains nothing from them
     float4 *d_sprims = nullptr, *d_sprims_planes = nullptr, *d_sshade = nullptr;
-    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_cmask = nullptr;
+    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_smask_enclosed = nullptr, *d_cmask = nullptr;
+    std::vector<float4> enclosing; // (centre, radius) of the spheres PTGPU_CULL_ENCLOSED took out of a set
     float4 *d_cbounds = nullptr;
     // BVH (device_params.h): one block + the id tables in each build's numbering
     float4 *d_bvh = nullptr;
@@ -130,9 +131,10 @@ void free_scene(ptgpu_ctx *c) {
     c->n_hnodes = 0;
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
+    if (c->d_smask_enclosed) (void)hipFree(c->d_smask_enclosed);
     c->d_sprims = nullptr;
     c->d_sprims_planes = nullptr;
-    c->d_smask_safe = c->d_smask_tight = nullptr;
+    c->d_smask_safe = c->d_smask_tight = c->d_smask_enclosed = nullptr;
     c->d_prims = c->d_shade = c->d_lights = nullptr;
     c->d_segs = nullptr;
     c->have_scene = false;
@@ -159,6 +161,7 @@ float as_float(int v) {
     return f;
 }
 
+constexpr double kEnclosedMargin = 1e-5; // "inside a sphere" = closer to its centre than r (1 - margin)
 PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     PtDeviceParams p{};
     p.prims = c->d_prims;
@@ -194,17 +197,29 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.tile_stride = 1;
     p.n_launch_tiles = p.n_tiles;
     int cull = c->shadow_cull;
-    if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_TIGHT;
+    if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_ENCLOSED;
+    if (cull == PTGPU_CULL_ENCLOSED) {
+        // the rule holds for paths that start inside every sphere it dropped: camera rays leave from
+        // orig + 0.1 rdir (main-cpu.c:76), |rdir| < 3 for any sane field of view, so one unit of margin
+        for (const float4 &s : c->enclosing) {
+            const double dx = c->camera.orig.x - s.x, dy = c->camera.orig.y - s.y, dz = c->camera.orig.z - s.z;
+            if (!(std::sqrt(dx * dx + dy * dy + dz * dz) <= (double)s.w * (1 - kEnclosedMargin) - 1.0)) cull = PTGPU_CULL_TIGHT;
+        }
+    }
     p.sprims = c->d_sprims;
     p.sshade = c->d_sshade;
-    p.smask = cull == PTGPU_CULL_SAFE ? c->d_smask_safe : cull == PTGPU_CULL_TIGHT ? c->d_smask_tight : nullptr;
+    p.smask = cull == PTGPU_CULL_SAFE       ? c->d_smask_safe
+              : cull == PTGPU_CULL_TIGHT    ? c->d_smask_tight
+              : cull == PTGPU_CULL_ENCLOSED ? c->d_smask_enclosed
+                                            : nullptr;
     p.n_sph_real = (int)c->info.spheres;
     p.sg_sph = c->sg_sph;
     p.sg_tri = c->sg_tri;
     p.mw_sph = c->mw_sph;
     p.mw_tri = c->mw_tri;
     // ray binning on triangle clusters: fast build, TIGHT sets only (the bins are built from them)
-    const bool bins = c->ray_bins && cull == PTGPU_CULL_TIGHT && p.smask && c->math == PTGPU_MATH_FAST;
+    const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED) && p.smask &&
+                      c->math == PTGPU_MATH_FAST;
     p.n_clusters = bins ? c->n_clusters : 0;
     p.cmask = c->d_cmask;
     p.cbounds = c->d_cbounds;
@@ -239,10 +254,11 @@ struct ShadowTables {
     std::vector<unsigned long long> cluster_masks;   // (1 + clusters) x mw_tri words
     std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
     std::vector<float4> hyb_nodes;                   // hierarchy whose leaves are the triangle groups
-    std::vector<unsigned long long> safe, tight;
+    std::vector<unsigned long long> safe, tight, enclosed;
+    std::vector<float4> enclosing;                   // spheres ENCLOSED dropped from at least one set
     bool tables_built = false;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
-    double mean_safe = 0, mean_tight = 0; // primitives tested per shadow ray, light-averaged
+    double mean_safe = 0, mean_tight = 0, mean_enclosed = 0; // primitives tested per shadow ray, light-averaged
 };
 
 struct D3 { double x, y, z; };
@@ -254,13 +270,17 @@ D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x
 double len(D3 a) { return std::sqrt(dot(a, a)); }
 
 // keep[l * n_prims + i] = primitive i may occlude a shadow ray towards light l under `mode`
-// (PTGPU_CULL_SAFE / PTGPU_CULL_TIGHT; anything else keeps everything).
-// prims: 3 quads per primitive in index order; types[i]: PT_SPHERE / PT_TRIANGLE; lights: 4 quads each.
+// (PTGPU_CULL_SAFE / TIGHT / ENCLOSED, ptgpu.h; anything else keeps everything).
+// prims: 3 quads per primitive in index order; types[i]: PT_SPHERE / PT_TRIANGLE; lights: 4 quads each;
+// dielectric[i]: primitive i refracts (paths pass through it: it encloses nothing).
 std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const std::vector<int> &types,
-                                       const std::vector<float4> &lights, int mode) {
+                                       const std::vector<float4> &lights, const std::vector<uint8_t> &dielectric,
+                                       int mode) {
     const size_t n_prims = types.size(), n_lights = lights.size() / 4;
     std::vector<uint8_t> keep(n_lights * n_prims, 1);
-    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT) return keep;
+    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED) return keep;
+    const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED;
+    if (enclosed_rule) mode = PTGPU_CULL_TIGHT;
     const double eps = (double)PT_EPSILON;
     for (size_t l = 0; l < n_lights; ++l) {
         int light_type;
@@ -282,6 +302,11 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
                 const D3 c = sub(d3(prims[3 * i]), p0);
                 const double r = std::fabs((double)prims[3 * i].w);
                 all_behind = behind(dot(c, n) + r, len(c) + r);
+                // ENCLOSED: the light's three corners strictly inside an opaque sphere (a NaN keeps it)
+                if (enclosed_rule && !dielectric[i]) {
+                    const double inside = r * (1 - kEnclosedMargin);
+                    if (len(c) <= inside && len(sub(c, e1)) <= inside && len(sub(c, e2)) <= inside) all_behind = true;
+                }
             } else {
                 const D3 a = sub(d3(prims[3 * i]), p0);
                 const D3 b = add(a, d3(prims[3 * i + 1])), c = add(a, d3(prims[3 * i + 2]));
@@ -373,7 +398,7 @@ std::vector<int> find_clusters(const std::vector<float4> &prims, const std::vect
 }
 
 void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int> &types,
-                         const std::vector<float4> &lights, ShadowTables &t) {
+                         const std::vector<float4> &lights, const std::vector<uint8_t> &dielectric, ShadowTables &t) {
     t.cluster_of = find_clusters(prims, types, t.cluster_bounds);
     const int n_clusters = (int)t.cluster_bounds.size();
     // shadow order: spheres; then the triangles of cluster 0, 1, ... each padded to whole groups;
@@ -382,6 +407,19 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     auto pad = [](std::vector<int> &v, int g) { while (v.size() % g) v.push_back(-1); };
     for (size_t i = 0; i < types.size(); ++i)
         if (types[i] == PT_SPHERE) sph_slots.push_back((int)i);
+    const size_t n_lights = lights.size() / 4, n_prims = types.size();
+    // lights x primitives decisions: beyond 2^26 of them the tables are not built and every shadow
+    // ray scans everything, as upstream
+    t.tables_built = (double)n_lights * (double)n_prims <= (double)(1u << 26);
+    std::vector<uint8_t> keep_enclosed;
+    if (t.tables_built) {
+        // spheres that most lights still have to test come first, so that they share groups
+        keep_enclosed = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_ENCLOSED);
+        std::vector<size_t> users(n_prims, 0);
+        for (size_t l = 0; l < n_lights; ++l)
+            for (int i : sph_slots) users[i] += keep_enclosed[l * n_prims + i];
+        std::stable_sort(sph_slots.begin(), sph_slots.end(), [&](int a, int b) { return users[a] > users[b]; });
+    }
     pad(sph_slots, kSphereGroup);
     // Triangle order = leaf order of a hierarchy whose leaves never mix clusters (bvh_build.h,
     // keyed build): the groups of 4 below are its leaves, cluster by cluster, unclustered last.
@@ -437,10 +475,11 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     for (int g = 0; g < t.sg_tri; ++g)
         t.cluster_masks[(size_t)(1 + cluster_of_group(g)) * t.mw_tri + g / 64] |= 1ull << (g % 64);
 
-    const size_t n_lights = lights.size() / 4, n_prims = types.size();
     const int words = t.mw_sph + t.mw_tri;
     auto masks = [&](int mode, std::vector<unsigned long long> &out, double &mean) {
-        const std::vector<uint8_t> keep = shadow_candidates(prims, types, lights, mode);
+        const std::vector<uint8_t> keep = mode == PTGPU_CULL_ENCLOSED
+                                              ? keep_enclosed
+                                              : shadow_candidates(prims, types, lights, dielectric, mode);
         out.assign(n_lights * words, 0ull);
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
@@ -455,17 +494,24 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         }
         mean = n_lights ? total / n_lights : 0;
     };
-    // lights x primitives decisions: beyond 2^26 of them (or 8 MiB of masks) the tables are not built
-    // and every shadow ray scans everything, as upstream
-    t.tables_built = (double)n_lights * (double)n_prims <= (double)(1u << 26) &&
-                     (double)n_lights * words * sizeof(unsigned long long) <= (double)(8u << 20);
+    // ... nor beyond 8 MiB of masks
+    t.tables_built = t.tables_built && (double)n_lights * words * sizeof(unsigned long long) <= (double)(8u << 20);
     if (!t.tables_built) {
-        t.mean_safe = t.mean_tight = (double)n_prims;
+        t.mean_safe = t.mean_tight = t.mean_enclosed = (double)n_prims;
         t.light_clusters.assign(n_lights, 0u);
         return;
     }
     masks(PTGPU_CULL_SAFE, t.safe, t.mean_safe);
     masks(PTGPU_CULL_TIGHT, t.tight, t.mean_tight);
+    masks(PTGPU_CULL_ENCLOSED, t.enclosed, t.mean_enclosed);
+    {
+        const std::vector<uint8_t> tight = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_TIGHT);
+        for (size_t i = 0; i < n_prims; ++i) {
+            bool dropped = false;
+            for (size_t l = 0; l < n_lights && !dropped; ++l) dropped = tight[l * n_prims + i] && !keep_enclosed[l * n_prims + i];
+            if (dropped) t.enclosing.push_back(prims[3 * i]); // (centre, radius)
+        }
+    }
 
     // per light: the clusters with a group in its TIGHT set (the ones a ray towards it is binned on)
     t.light_clusters.assign(n_lights, 0u);
@@ -480,6 +526,7 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
 struct PackedScene {
     std::vector<float4> prims, lights;
     std::vector<int> types, object_of_prim;
+    std::vector<uint8_t> dielectric; // per primitive: material slot 2, upstream's built-in glass (displayfunc.c:139-150)
 };
 void pack_geometry(const pt_object *objects, uint32_t object_count, uint32_t light_count, PackedScene &g) {
     for (uint32_t i = 0; i < object_count; ++i) {
@@ -487,6 +534,7 @@ void pack_geometry(const pt_object *objects, uint32_t object_count, uint32_t lig
         if (o.type != PT_SPHERE && o.type != PT_TRIANGLE) continue; // MODEL placeholders and junk are skipped
         g.types.push_back((int)o.type);
         g.object_of_prim.push_back((int)i);
+        g.dielectric.push_back(o.material_id == 2);
         if (o.type == PT_SPHERE) {
             g.prims.push_back(make_float4(o.center.x, o.center.y, o.center.z, o.radius));
             g.prims.push_back(make_float4(o.radius * o.radius, 0.f, 0.f, 0.f));
@@ -673,7 +721,7 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         ctx->waves_per_group = value;
         return PTGPU_OK;
     case PTGPU_OPT_SHADOW_CULL:
-        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_AUTO)
+        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_ENCLOSED)
             return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
         ctx->shadow_cull = value;
         return PTGPU_OK;
@@ -727,6 +775,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
 
         pt_material m{};
         if (!light) m = materials[o.material_id];
+        if ((int)m.type == 2) geo.dielectric[p] = 1; // whatever slot the caller's table keeps its glass in
         const int flags = ((int)m.type & 0xff) | ((light ? 1 : 0) << 8) | (((int)o.type & 0xff) << 16);
         shade.push_back(make_float4(o.emission.x, o.emission.y, o.emission.z, as_float(flags)));
         shade.push_back(make_float4(o.color.x, o.color.y, o.color.z, m.sigma));
@@ -756,7 +805,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     // are kept only when they pay (TIGHT removes at least a tenth of the tests, light-averaged)
     // and stay small.
     ShadowTables st;
-    build_shadow_tables(prims, types, lights, st);
+    build_shadow_tables(prims, types, lights, geo.dielectric, st);
     if (info.lights >= (1u << 18)) st.cluster_bounds.clear(); // the near-queue tag holds 18 bits of light index
     for (size_t l = 0; l < st.light_clusters.size(); ++l)   // l1.w is free in both light kinds
         dlights[kLightQuads * l + 1].w = as_float(st.cluster_bounds.empty() ? 0 : (int)st.light_clusters[l]);
@@ -767,6 +816,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     info.shadow_groups = (uint32_t)(st.sg_sph + st.sg_tri);
     info.shadow_tests_safe = use_tables ? (float)st.mean_safe : (float)info.primitives;
     info.shadow_tests_tight = use_tables ? (float)st.mean_tight : (float)info.primitives;
+    info.shadow_tests_enclosed = use_tables ? (float)st.mean_enclosed : (float)info.primitives;
     auto fits = [](size_t bytes) { return bytes <= kMaxStagedLdsBytes ? (uint32_t)bytes : 0u; };
     const size_t light_bytes = dlights.size() * sizeof(float4), shadow_bytes = st.sprims.size() * sizeof(float4);
     const uint32_t lds_strict = fits(prims.size() * sizeof(float4) + light_bytes);
@@ -825,6 +875,8 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     if (use_tables) {
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));
         HIP_TRY(upload(ctx->d_smask_tight, st.tight));
+        HIP_TRY(upload(ctx->d_smask_enclosed, st.enclosed));
+        ctx->enclosing = st.enclosing;
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
         HIP_TRY(upload(ctx->d_cbounds, st.cluster_bounds));
     }
@@ -865,8 +917,8 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
 int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count, int mode,
                             uint8_t *keep, uint32_t *n_lights) {
     if (!objects || !n_lights) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: null argument");
-    if (mode < PTGPU_CULL_OFF || mode > PTGPU_CULL_TIGHT)
-        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE or TIGHT");
+    if (mode != PTGPU_CULL_OFF && mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE, TIGHT or ENCLOSED");
     PackedScene geo;
     pack_geometry(objects, object_count, light_count, geo);
     *n_lights = (uint32_t)(geo.lights.size() / 4);
@@ -875,7 +927,7 @@ int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uin
         return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: %u lights x %zu primitives is beyond the size the "
                                         "tables are built for (set_scene scans everything for such a scene)",
                     *n_lights, geo.types.size());
-    const std::vector<uint8_t> by_prim = shadow_candidates(geo.prims, geo.types, geo.lights, mode);
+    const std::vector<uint8_t> by_prim = shadow_candidates(geo.prims, geo.types, geo.lights, geo.dielectric, mode);
     const size_t n_prims = geo.types.size();
     memset(keep, 0, (size_t)*n_lights * object_count);
     for (size_t l = 0; l < *n_lights; ++l)

@@ -222,7 +222,7 @@ OPT_SHADOW_CULL = 6
 OPT_RAY_BINS = 7
 OPT_BVH = 8
 BVH_OFF, BVH_ON, BVH_AUTO = 0, 1, 2
-CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO = 0, 1, 2, 3
+CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED = 0, 1, 2, 3, 4
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
@@ -232,7 +232,7 @@ class SceneInfo(C.Structure):
     _fields_ = ([(n, C.c_uint32) for n in ("primitives", "spheres", "triangles", "lights", "segments",
                                           "lds_bytes", "shadow_groups")]
                 + [("shadow_tests_safe", C.c_float), ("shadow_tests_tight", C.c_float),
-                   ("clusters", C.c_uint32), ("clustered_triangles", C.c_uint32),
+                   ("shadow_tests_enclosed", C.c_float), ("clusters", C.c_uint32), ("clustered_triangles", C.c_uint32),
                    ("bvh_nodes", C.c_uint32), ("bvh_primitives", C.c_uint32)])
 
 

@@ -157,6 +157,31 @@ def test_shadow_cull_tight_equals_its_cpu_replay_bitwise(kernel):
     assert (pixels == cpu.pixels).all()
 
 
+@pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
+def test_shadow_cull_enclosed_equals_its_cpu_replay_and_falls_back_outside(kernel):
+    # ENCLOSED (the fast build's default) is a fixed algorithm too: strict build == oracle replay
+    name, w, h, spp = "cornell", 96, 72, 3
+    sc = pt.LoadedScene(name, w, h)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_ENCLOSED)):
+        cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_ENCLOSED)
+    assert (sd == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all()
+    # a camera outside the walls: paths are no longer inside the spheres the rule dropped, and the
+    # library renders with the TIGHT sets (bit-identical to asking for TIGHT)
+    out = []
+    for cull in (pt.CULL_ENCLOSED, pt.CULL_TIGHT):
+        g = pt.Gpu(0, 0, kernel=kernel, math=pt.MATH_STRICT, shadow_cull=cull)
+        g.set_scene(sc)
+        cam = pt.Camera.from_buffer_copy(sc.camera)
+        cam.orig.z = 400.0                                     # beyond the front wall (z = 270)
+        g.set_camera(cam)
+        g.resize(w, h, pt.seed_block(w, h))
+        g.render(2)
+        out.append((g.colors(), g.seeds()))
+        g.close()
+    assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all()
+
+
 def test_shadow_cull_full_size_cornell_safe_is_brute_force():
     # 1024x768 x 4 passes: ~8e8 shadow rays; SAFE and OFF must agree in every bit (NaN pixels included)
     w, h, spp = 1024, 768, 4
@@ -203,7 +228,7 @@ def test_scene_info_reports_shadow_tables_and_clusters():
     g.set_scene(pt.LoadedScene("obj-model", 32, 24))                        # nothing to cull: no tables, no bins
     info = g.scene_info()
     assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 322
-    for opt, bad in ((pt.OPT_SHADOW_CULL, 4), (pt.OPT_SHADOW_CULL, -1), (9, 0)):
+    for opt, bad in ((pt.OPT_SHADOW_CULL, 5), (pt.OPT_SHADOW_CULL, -1), (9, 0)):
         with pytest.raises(pt.GpuError):
             g.set_option(opt, bad)
     g.close()

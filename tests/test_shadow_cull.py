@@ -6,7 +6,10 @@ What is proven here on the CPU
     scenes, both integrators - the same bar as the brute-force scan;
   * TIGHT is a subset of SAFE, culls only primitives that lie in the closed half-space behind the
     light's plane, and moves the image by less than the calibrated FP floor (it can differ only for
-    rays that graze the light's own plane, where the contribution's cosine factor is ~0).
+    rays that graze the light's own plane, where the contribution's cosine factor is ~0);
+  * ENCLOSED is TIGHT minus the opaque spheres a triangle light lies wholly inside, moves the image
+    by about 1e-4 of its radiance (upstream's float "acne" on the sphere a shadow ray starts from),
+    and never drops a dielectric sphere or a sphere the light pokes out of.
 """
 import numpy as np
 import pytest
@@ -112,3 +115,47 @@ def test_counting_replay_reports_fewer_tests_and_same_draws():
     assert (a.rng_draws, a.light_samples, a.extension_rays, a.shadow_rays) == \
            (b.rng_draws, b.light_samples, b.extension_rays, b.shadow_rays)
     assert b.triangle_tests < 0.8 * a.triangle_tests
+
+
+def test_enclosed_drops_only_opaque_spheres_around_the_light():
+    sc = pt.LoadedScene("cornell", 32, 24)
+    o, real, lights = geometry(sc)
+    tight = pt.shadow_candidates(sc, pt.CULL_TIGHT)
+    enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
+    assert (enc <= tight).all()
+    changed = np.argwhere(tight != enc)
+    assert len(changed) > 500                                   # ~5 of the 6 wall spheres for each of 123 lights
+    for l, i in changed:
+        li = lights[l]
+        assert o["type"][i] == 0 and o["type"][li] == 1 and o["material_id"][i] != 2
+        c, r = o["center"][i].astype(np.float64), float(o["radius"][i])
+        for v in (o["p1"][li], o["p2"][li], o["p3"][li]):
+            assert np.linalg.norm(v.astype(np.float64) - c) <= r * (1 - 1e-5)
+    # the cylinder stands in the floor (its lower rim is at y = -8, the floor sphere's top at y = 0):
+    # the lights that reach below it keep the floor sphere, and nothing else is kept of the walls
+    walls = np.nonzero((o["type"] == 0) & (o["radius"] >= 1000))[0]
+    floor = [i for i in walls if o["center"][i][1] > 9000][0]
+    kept = enc[:, walls].sum(0)
+    assert kept[list(walls).index(floor)] > 30 and kept.sum() == kept[list(walls).index(floor)]
+    # a glass wall encloses nothing: paths leave through it
+    sc.objects["material_id"][walls] = 2
+    glass = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
+    assert (glass == tight).all()
+
+
+def test_enclosed_replay_moves_cornell_by_its_acne_only():
+    w, h, spp = 96, 72, 6
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_TIGHT)):
+        tight = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_ENCLOSED)):
+        enc = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    assert (tight.seeds == enc.seeds).all()                     # draws never depend on a shadow test
+    ok = ~(np.isnan(tight.colors).any(1) | np.isnan(enc.colors).any(1))
+    d = enc.colors[ok].astype(np.float64) - tight.colors[ok]
+    mean = float(tight.colors[ok].mean())
+    print(f"ENCLOSED vs TIGHT on the CPU: {(np.abs(d).max(1) > 0).mean():.3f} of the pixels differ, "
+          f"mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} of the radiance")
+    assert (d >= -1e-6).all()                                   # only occlusions are lost: nothing gets darker
+    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean

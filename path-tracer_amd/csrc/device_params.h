@@ -22,11 +22,15 @@
 //                               light is rejected there (geomfunc.h:276-285).  Read by the fast build only.
 //
 // Shadow-ray tables (optional, see PTGPU_OPT_SHADOW_CULL in ptgpu.h):
-//   sprims [3 * (6 sg_sph + 4 sg_tri)]  the same primitive records in shadow order: all spheres,
-//                          padded to a multiple of kSphereGroup with never-hit records, then all
-//                          triangles, padded to a multiple of kTriGroup.  A group = that many
-//                          consecutive primitives of one type, tested back to back.
+//   sprims [3 * (sg_sph + 4 sg_tri)]  the same primitive records in shadow order: all spheres
+//                          (those that most lights keep under ENCLOSED first), padded to a multiple
+//                          of kSphereGroup with never-hit records, then all triangles, padded to a
+//                          multiple of kTriGroup.  A group = that many consecutive primitives of
+//                          one type, tested back to back.
 //                          (An any-hit scan does not depend on the visiting order.)
+//     The fast build (outside its BVH translation unit) reads its own copy of this array, with the
+//     triangles in PLANE FORM (radiance_device.inc, triangle_planes_t):
+//       q0 = (n, n.p1)  q1 = (n1, -n1.p1)  q2 = (n2, -n2.p1),  n = e1 x e2, n1 = e2 x n / n.n, n2 = n x e1 / n.n
 //     Triangles are ordered cluster by cluster (connected components of the meshes, the 8 largest
 //     with >= 8 triangles), each cluster padded to whole groups, unclustered triangles last.
 //   smask  [n_lights * (mw_sph + mw_tri)]  per light, 64-bit words: bit g of the first mw_sph words
@@ -49,7 +53,8 @@
 
 constexpr int kLightQuads = 5;
 constexpr int kSphereGroup = 1, kTriGroup = 4; // primitives per shadow group, tested back to back with no exit check
-                                               // in between (6: the wall spheres of a room are one group; measured 2: -3.7 %)
+                                               // in between.  One sphere per group: with ENCLOSED most rays test one sphere
+                                               // or none, and the device scan stays equal to the set sphere for sphere
 
 struct PtDeviceParams {
     const float4 *prims;

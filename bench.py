@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = `--passes` progressive passes (one path per pixel per pass) over the whole frame, issued
-through the C-ABI as ONE kernel launch.  Inputs (scene records, seeds, colour buffer) are resident
+through the C-ABI as ONE render call (the library splits it into launches: per pass and image region
+for this workload).  Inputs (scene records, seeds, colour buffer) are resident
 in HBM before the timed region; the region is K steps bracketed by a barrier + device sync, MAX over
 ranks.  With N > 1 each rank renders from its own seed block and the colour buffers are summed with
 one RCCL all-reduce inside the timed region (weak scaling: per-GPU work is fixed).
@@ -76,7 +77,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--passes", type=int, default=8, help="progressive passes per step (= per launch)")
+    ap.add_argument("--passes", type=int, default=32,
+                    help="progressive passes per step (the reference's frame after warm-up is 0.5 s of passes, "
+                         "main-gpu.c:774-794: hundreds at this rate)")
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=768)

@@ -67,9 +67,10 @@ enum {
     PTGPU_KERNEL_WAVEFRONT = 1, /* wave-autonomous wavefront tracer: shadow rays compacted into
                                    per-wave LDS queues and traced by dense 64-lane batches       */
     PTGPU_KERNEL_AUTO      = 2  /* WAVEFRONT for the path-tracing integrator on scenes with two or
-                                   more lights (the shadow-ray queues are what it is for), MEGA
-                                   otherwise (measured 5-15 % faster on one-light scenes and for
-                                   the direct-lighting integrator); same results either way      */
+                                   more lights (the shadow-ray queues are what it is for) or with
+                                   a hierarchy over 512 or more triangles, MEGA otherwise (measured
+                                   5-15 % faster on one-light scenes and for the direct-lighting
+                                   integrator); same results either way                          */
 };
 /* Shadow rays are only cast towards the FRONT of a triangle light (geomfunc.h:276-285 rejects a
  * sample whose direction has a positive cosine with the light's normal), so a primitive that lies

@@ -580,10 +580,14 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);
 
     // AUTO: the shadow-ray queues pay with two or more lights and incoherent hit points; the direct
-    // lighting integrator stops at the (tile-coherent) first hit, where the inline loop is ahead
+    // lighting integrator stops at the (tile-coherent) first hit, where the inline loop is ahead.
+    // A large triangle hierarchy is the other case for the wavefront kernel (its shadow rays walk
+    // the tree in dense batches): large-object 614 -> 940, the bunny scene 161 -> 184 Mpaths/s; a
+    // sphere hierarchy or a small mesh is not (complex 2 235 -> 2 081, table-and-mirror 1 772 -> 1 509).
+    const bool big_mesh = probe.n_bnodes > 0 && probe.bvh_type == PT_TRIANGLE && probe.n_bslots >= 512;
     const int kernel = c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
-                       : (c->info.lights >= 2 && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
-                                                                                    : PTGPU_KERNEL_MEGA);
+                       : ((c->info.lights >= 2 || big_mesh) && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
+                                                                                                 : PTGPU_KERNEL_MEGA);
     auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
         const bool strict = c->math == PTGPU_MATH_STRICT;
         if (p.n_bnodes) { // the BVH builds of the same kernels

@@ -46,7 +46,10 @@
 // bvh_ids[slot] / bvh_rest_ids[r] = the primitive's index in the build's own numbering (index order
 // for the strict build, shadow order for the fast build): what load_surface takes and what breaks
 // a tie between equal distances.  While the BVH is active the block is staged in LDS in place of
-// the build's primary primitive array and the per-light candidate sets are off.
+// the build's primary primitive array and the per-light candidate sets are off.  A block too large
+// for LDS whose nodes alone fit (a mesh of ~1 500 to ~5 600 triangles: 16 B of nodes per triangle
+// against 48 B of records) is staged nodes only, for the wavefront kernel: the walk - most of the
+// accesses - stays in LDS and each lane reads the few leaves it reaches from global memory.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -93,6 +96,7 @@ struct PtDeviceParams {
     const float4 *bvh;
     const int *bvh_ids, *bvh_rest_ids;
     int n_bnodes, n_bslots, n_brest, bvh_type;
+    int bvh_nodes_only;   // 1: only the nodes (and the lights) are staged in LDS, leaves are read from global memory
     // hybrid (fast build with candidate sets): a hierarchy whose leaves are the triangle groups of
     // sprims (leaf `first` = slot within the triangle section); n_hnodes == 0 switches it off
     const float4 *hyb_nodes;

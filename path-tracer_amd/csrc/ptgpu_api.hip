@@ -83,7 +83,7 @@ struct ptgpu_ctx {
     float4 *d_hyb_nodes = nullptr;     // hierarchy over the shadow order (hybrid)
     int n_hnodes = 0;
     uint32_t lds_fast_hyb = 0;
-    uint32_t lds_bvh = 0;
+    uint32_t lds_bvh = 0, lds_bvh_nodes = 0; // whole block + lights; nodes + lights (when the block does not fit)
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
     uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
@@ -562,13 +562,6 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     if (n_passes == 0) return PTGPU_OK;
     PtLaunchConfig cfg{};
     PtDeviceParams probe = make_params(c, first_sample, 1);
-    const uint32_t stage_bytes = probe.n_bnodes            ? c->lds_bvh
-                                 : probe.n_hnodes           ? c->lds_fast_hyb
-                                 : c->math == PTGPU_MATH_FAST ? c->lds_fast
-                                 : probe.smask               ? c->lds_strict_cull
-                                                             : c->lds_strict;
-    cfg.use_lds = c->want_lds && stage_bytes > 0;
-    cfg.lds_bytes = cfg.use_lds ? stage_bytes : 0;
     cfg.waves_per_group = c->waves_per_group;
     // One region per stream when the image has enough tiles to keep every region's launch wide.
     // Cheap scenes (a pass is tens of microseconds) gain nothing from overlapping tails and lose to
@@ -588,6 +581,18 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     const int kernel = c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
                        : ((c->info.lights >= 2 || big_mesh) && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
                                                                                                  : PTGPU_KERNEL_MEGA);
+    // a hierarchy too large for LDS is staged nodes only, where that pays: the wavefront kernel
+    // (one large workgroup per CU shares the nodes; the mega kernel's 4-wave groups would each
+    // hold a copy)
+    const bool nodes_only = probe.n_bnodes && c->lds_bvh == 0 && c->lds_bvh_nodes > 0 && kernel == PTGPU_KERNEL_WAVEFRONT;
+    const uint32_t stage_bytes = nodes_only                  ? c->lds_bvh_nodes
+                                 : probe.n_bnodes            ? c->lds_bvh
+                                 : probe.n_hnodes           ? c->lds_fast_hyb
+                                 : c->math == PTGPU_MATH_FAST ? c->lds_fast
+                                 : probe.smask               ? c->lds_strict_cull
+                                                             : c->lds_strict;
+    cfg.use_lds = c->want_lds && stage_bytes > 0;
+    cfg.lds_bytes = cfg.use_lds ? stage_bytes : 0;
     auto launch = [&](const PtDeviceParams &p, hipStream_t s) -> int {
         const bool strict = c->math == PTGPU_MATH_STRICT;
         if (p.n_bnodes) { // the BVH builds of the same kernels
@@ -610,6 +615,7 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
         const int n = (n_passes - done < chunk) ? n_passes - done : chunk;
         for (int r = 0; r < regions; ++r) {
             PtDeviceParams p = make_params(c, first_sample + done, n);
+            p.bvh_nodes_only = nodes_only && cfg.use_lds;
             p.tile_first = r;
             p.tile_stride = regions;
             p.n_launch_tiles = (p.n_tiles - r + regions - 1) / regions;
@@ -857,6 +863,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     }
     const size_t in_tree = bvh.prim_of_slot.size() ? types.size() - bvh.rest.size() : 0;
     const uint32_t lds_bvh = fits(bvh_block.size() * sizeof(float4) + light_bytes);
+    const uint32_t lds_bvh_nodes = fits(bvh.nodes.size() * sizeof(float4) + light_bytes);
     info.bvh_nodes = (uint32_t)(bvh.nodes.size() / 2);
     info.bvh_primitives = (uint32_t)in_tree;
 
@@ -902,6 +909,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     }
     ctx->lds_fast_hyb = lds_fast_hyb;
     ctx->lds_bvh = lds_bvh;
+    ctx->lds_bvh_nodes = lds_bvh_nodes;
     ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
     info.clusters = (uint32_t)ctx->n_clusters;
     for (int c : st.cluster_of) info.clustered_triangles += (ctx->n_clusters && c >= 0) ? 1u : 0u;

@@ -100,6 +100,20 @@ def test_bvh_full_size_equals_linear_scan(name, lds):
     assert same_bits(off[0], on[0]) and (off[1] == on[1]).all() and (off[2] == on[2]).all()
 
 
+def test_bvh_nodes_only_staging_equals_the_other_paths():
+    # 5 050 triangles: the block (320 KB) does not fit LDS, its nodes (81 KB) do - the wavefront
+    # kernel stages the nodes only and reads leaves from global memory; same bits as everything global
+    # in both builds, and (strict build: one order of summation) as the mega kernel
+    w, h, spp = 256, 192, 2
+    for math in (pt.MATH_STRICT, pt.MATH_FAST):
+        ref = gpu_render("obj-model-bunny", w, h, spp, 0, pt.KERNEL_WAVEFRONT, math, lds=0)
+        for kernel, lds in ((pt.KERNEL_WAVEFRONT, 1), (pt.KERNEL_MEGA, 1)):
+            if kernel == pt.KERNEL_MEGA and math == pt.MATH_FAST:
+                continue
+            got = gpu_render("obj-model-bunny", w, h, spp, 0, kernel, math, lds=lds)
+            assert same_bits(ref[0], got[0]) and (ref[1] == got[1]).all() and (ref[2] == got[2]).all(), (math, kernel)
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
 @pytest.mark.parametrize("lds", [1, 0])
 def test_hybrid_extension_hierarchy_is_bit_identical_in_the_fast_build(kernel, lds):

@@ -15,7 +15,8 @@ g.render(n); g.finish()
 lib.ptgpu_debug_stats(buf, 0)
 names = ["light iterations", "skipped (whole wave behind)", "lanes that may face", "lanes that want a ray", "rays to near queue",
          "far batches", "rays in far batches", "near batches", "rays in near batches", "light-phase calls", "diffuse lanes at calls",
-         "sample batches", "candidates in sample batches"]
+         "sample batches", "candidates in sample batches", "sphere groups scanned by near batches",
+         "triangle groups scanned by near batches", "lights spanned by near batches"]
 v = [int(x) for x in buf]
 paths = w * h * n
 for k, name in enumerate(names):
@@ -24,3 +25,4 @@ it = v[0]
 print(f"skipped iterations {v[1] / it:.3f}; in the other iterations: candidates {v[2] / (it - v[1]):.1f} / 64, of which want a ray {v[3] / max(v[2], 1):.3f}")
 print(f"sample batch fill {v[12] / max(v[11], 1):.1f}")
 print(f"near share of rays {v[4] / max(v[3], 1):.3f}; far batch fill {v[6] / max(v[5], 1):.1f}; near batch fill {v[8] / max(v[7], 1):.1f}; diffuse lanes per call {v[10] / max(v[9], 1):.1f}")
+print(f"per near batch: {v[13] / max(v[7], 1):.2f} spheres, {v[14] / max(v[7], 1):.2f} triangle groups, {v[15] / max(v[7], 1):.1f} lights spanned")

@@ -50,7 +50,14 @@ enum {
                                         towards a one-sided triangle light is tested against     */
     PTGPU_OPT_RAY_BINS = 7,          /* 1 (default) = fast build with TIGHT sets bins shadow rays on
                                         triangle clusters (wavefront kernel); 0 = one queue        */
-    PTGPU_OPT_BVH = 8                /* PTGPU_BVH_* (default AUTO)                                  */
+    PTGPU_OPT_BVH = 8,               /* PTGPU_BVH_* (default AUTO)                                  */
+    PTGPU_OPT_WORK_QUEUE = 9         /* wavefront kernel: 1 = a render call is ONE launch that fills the
+                                        chip once, its waves taking (pass, tile) units from a queue in
+                                        device memory (no drain between passes; a tile's passes stay in
+                                        order); 0 = a launch per pass and image region
+                                        (PTGPU_OPT_STREAMS); 2 (default) = 1 where a unit is heavy
+                                        enough to pay for its queue traffic (>= 2048 tiles and
+                                        primitives x (1 + lights) >= 512).  Same image either way.   */
 };
 /* Intersect / IntersectP (geomfunc.h:126-193) scan every object.  For a scene whose cost is that
  * scan over one large mesh the kernels can walk a bounding-volume hierarchy instead (each lane its

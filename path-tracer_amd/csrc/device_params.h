@@ -79,6 +79,11 @@ struct PtDeviceParams {
     // this launch covers tiles tile_first + k * tile_stride, k in [0, n_launch_tiles): the image is
     // dealt round-robin into regions so independent regions can run on concurrent streams
     int tile_first, tile_stride, n_launch_tiles;
+    // Work queue of the wavefront kernel (null: one tile per wave, as laid out above).  work[0] = the
+    // next unit, unit = pass * n_tiles + tile (pass-major, so a tile's passes are taken in order);
+    // work[1 + tile] = passes of this launch already stored for the tile; work[1 + n_tiles] = set
+    // when a wave gave up waiting (never, unless a wave died).  Zeroed by the host before the launch.
+    int *work;
     // shadow order: always present (the fast build traces every ray in it); smask == nullptr
     // switches the per-light candidate sets off
     const float4 *sprims;
@@ -107,6 +112,7 @@ struct PtLaunchConfig {
     int use_lds;          // stage prims+lights in LDS
     unsigned lds_bytes;   // dynamic LDS for the staged records (see stage_records)
     int waves_per_group;  // wavefront kernel: waves per workgroup (0 = default)
+    int compute_units;    // of the device (work-queue launches fill the chip once, no more)
 };
 
 namespace ptk_fast {

@@ -96,6 +96,10 @@ struct ptgpu_ctx {
     int width = 0, height = 0;
     float *d_colors = nullptr;
     uint32_t *d_pixels = nullptr, *d_seeds = nullptr;
+    int *d_work = nullptr;      // work queue of the wavefront kernel: 2 + tiles words (device_params.h)
+    int work_queue = 2;         // PTGPU_OPT_WORK_QUEUE
+    bool queue_in_flight = false; // a work-queue launch was issued since the last check of its give-up word
+    int compute_units = 0;
 };
 
 namespace {
@@ -144,6 +148,8 @@ void free_image(ptgpu_ctx *c) {
     if (c->d_colors) (void)hipFree(c->d_colors);
     if (c->d_pixels) (void)hipFree(c->d_pixels);
     if (c->d_seeds) (void)hipFree(c->d_seeds);
+    if (c->d_work) (void)hipFree(c->d_work);
+    c->d_work = nullptr;
     c->d_colors = nullptr;
     c->d_pixels = c->d_seeds = nullptr;
     c->width = c->height = 0;
@@ -606,6 +612,24 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
         return strict ? ptk_strict::launch_wavefront(p, cfg, s) : ptk_fast::launch_wavefront(p, cfg, s);
     };
 
+    cfg.compute_units = c->compute_units;
+    // Work queue (PTGPU_OPT_WORK_QUEUE): one launch for the whole call.  Each unit costs a shared
+    // counter increment and an agent-scope release / acquire (microseconds): AUTO takes it where a
+    // unit runs for a good fraction of a millisecond (cornell.txt 398 -> 468, large-object 947 ->
+    // 1 314 Mpaths/s) and not where a pass is cheap (materials.txt 6 129 -> 1 910 with it).
+    const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
+                       (c->work_queue == 1 || (c->work_queue == 2 && probe.n_tiles >= 2048 && work >= 512));
+    if (queue) {
+        PtDeviceParams p = make_params(c, first_sample, n_passes);
+        p.bvh_nodes_only = nodes_only && cfg.use_lds;
+        p.work = c->d_work;
+        // the counter and the per-tile words; the give-up word behind them is sticky until it is read
+        HIP_TRY(hipMemsetAsync(c->d_work, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
+        const int rc = launch(p, c->stream);
+        if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+        c->queue_in_flight = true;
+        return PTGPU_OK;
+    }
     int launch_error = 0;
     if (regions > 1) { // fork: side streams start after everything already queued on the main one
         HIP_TRY(hipEventRecord(c->fork_ev, c->stream));
@@ -663,6 +687,7 @@ int ptgpu_create(ptgpu_ctx **out, int device_ordinal, int integrator) {
     if (!c) return fail(PTGPU_ERR_MEMORY, "out of host memory");
     c->device = device_ordinal;
     c->integrator = integrator;
+    c->compute_units = prop.multiProcessorCount;
     auto make_queues = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&c->ev0));
@@ -741,6 +766,10 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         return PTGPU_OK;
     case PTGPU_OPT_RAY_BINS:
         ctx->ray_bins = value ? 1 : 0;
+        return PTGPU_OK;
+    case PTGPU_OPT_WORK_QUEUE:
+        if (value < 0 || value > 2) return fail(PTGPU_ERR_ARGUMENT, "work queue must be 0, 1 or 2 (automatic)");
+        ctx->work_queue = value;
         return PTGPU_OK;
     case PTGPU_OPT_PASSES_PER_LAUNCH:
         if (value < 0 || value > 64) return fail(PTGPU_ERR_ARGUMENT, "passes per launch must be 0..64");
@@ -975,6 +1004,10 @@ int ptgpu_resize(ptgpu_ctx *ctx, int width, int height, const uint32_t *seeds) {
     HIP_TRY(hipMalloc((void **)&ctx->d_colors, n * 3 * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&ctx->d_pixels, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_seeds, n * 2 * sizeof(uint32_t)));
+    const size_t work_words = 2 + (size_t)((width + 7) / 8) * ((height + 7) / 8);
+    HIP_TRY(hipMalloc((void **)&ctx->d_work, work_words * sizeof(int)));
+    HIP_TRY(hipMemset(ctx->d_work, 0, work_words * sizeof(int)));
+    ctx->queue_in_flight = false;
     HIP_TRY(hipMemset(ctx->d_colors, 0, n * 3 * sizeof(float)));
     HIP_TRY(hipMemset(ctx->d_pixels, 0, n * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(ctx->d_seeds, seeds, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1008,11 +1041,26 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
     return PTGPU_OK;
 }
 
+// after the stream has drained: did a wave of a work-queue launch give up waiting for a tile's
+// previous pass (device_params.h)?  It cannot, unless a wave died; the image would be incomplete.
+static int check_work_queue(ptgpu_ctx *ctx) {
+    if (!ctx->queue_in_flight || !ctx->d_work) return PTGPU_OK;
+    ctx->queue_in_flight = false;
+    const size_t tiles = (size_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
+    int gave_up = 0;
+    HIP_TRY(hipMemcpy(&gave_up, ctx->d_work + 1 + tiles, sizeof gave_up, hipMemcpyDeviceToHost));
+    if (gave_up) {
+        (void)hipMemset(ctx->d_work + 1 + tiles, 0, sizeof(int));
+        return fail(PTGPU_ERR_DEVICE, "work queue: a wave waited for a tile's previous pass beyond its limit; the frame is incomplete");
+    }
+    return PTGPU_OK;
+}
+
 int ptgpu_finish(ptgpu_ctx *ctx) {
     int rc = bind(ctx);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PTGPU_OK;
+    return check_work_queue(ctx);
 }
 
 static int read_back(ptgpu_ctx *ctx, void *dst, const void *src, size_t bytes, const char *what) {
@@ -1022,7 +1070,7 @@ static int read_back(ptgpu_ctx *ctx, void *dst, const void *src, size_t bytes, c
     if (!src) return fail(PTGPU_ERR_STATE, "%s before ptgpu_resize", what);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return PTGPU_OK;
+    return check_work_queue(ctx);
 }
 
 int ptgpu_read_pixels(ptgpu_ctx *ctx, uint32_t *pixels) {

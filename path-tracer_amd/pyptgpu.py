@@ -221,6 +221,7 @@ OPT_KERNEL, OPT_MATH, OPT_LDS, OPT_STREAMS, OPT_PASSES_PER_LAUNCH, OPT_WAVES_PER
 OPT_SHADOW_CULL = 6
 OPT_RAY_BINS = 7
 OPT_BVH = 8
+OPT_WORK_QUEUE = 9
 BVH_OFF, BVH_ON, BVH_AUTO = 0, 1, 2
 CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED = 0, 1, 2, 3, 4
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
@@ -298,7 +299,8 @@ class Gpu:
     """One ptgpu context driven the way main-gpu.c drives its OpenCL objects."""
 
     def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None, streams=None,
-                 passes_per_launch=None, waves_per_group=None, shadow_cull=None, ray_bins=None, bvh=None):
+                 passes_per_launch=None, waves_per_group=None, shadow_cull=None, ray_bins=None, bvh=None,
+                 work_queue=None):
         self.lib = gpu()
         self.ctx = C.c_void_p()
         self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
@@ -320,6 +322,8 @@ class Gpu:
             self.set_option(OPT_RAY_BINS, ray_bins)
         if bvh is not None:
             self.set_option(OPT_BVH, bvh)
+        if work_queue is not None:
+            self.set_option(OPT_WORK_QUEUE, work_queue)
         self.w = self.h = 0
         self.sample = 0
 

@@ -242,7 +242,7 @@ def test_scene_info_reports_shadow_tables_and_clusters():
     g.set_scene(pt.LoadedScene("obj-model", 32, 24))                        # nothing to cull: no tables, no bins
     info = g.scene_info()
     assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 322
-    for opt, bad in ((pt.OPT_SHADOW_CULL, 5), (pt.OPT_SHADOW_CULL, -1), (9, 0)):
+    for opt, bad in ((pt.OPT_SHADOW_CULL, 5), (pt.OPT_SHADOW_CULL, -1), (pt.OPT_WORK_QUEUE, 3), (10, 0)):
         with pytest.raises(pt.GpuError):
             g.set_option(opt, bad)
     g.close()
@@ -297,6 +297,26 @@ def test_pass_by_pass_equals_batched_and_is_deterministic(kernel):
             assert same_bits(x, y)
         for x, y in zip(a, c):
             assert same_bits(x, y)
+
+
+def test_work_queue_is_the_same_image_as_a_launch_per_pass():
+    # PTGPU_OPT_WORK_QUEUE: one launch whose waves take (pass, tile) units, against a launch per pass and
+    # region - every bit equal (colours, pixels, RNG state), both builds, at a size with several
+    # units per wave slot so that waves do wait for a tile's previous pass
+    w, h, spp = 1024, 768, 5
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    for math in (pt.MATH_FAST, pt.MATH_STRICT):
+        out = []
+        for q in (0, 1):
+            g = pt.Gpu(0, 0, kernel=pt.KERNEL_WAVEFRONT, math=math, work_queue=q)
+            g.set_scene(sc)
+            g.resize(w, h, seeds)
+            g.render(2)                       # two calls: the queue is reset between launches
+            g.render(spp - 2 if math == pt.MATH_FAST else 1)
+            out.append((g.colors(), g.pixels(), g.seeds()))
+            g.close()
+        assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all(), math
 
 
 def test_kernels_agree_with_each_other_bitwise():

@@ -88,7 +88,9 @@ def main():
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
     ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "auto"],
                     help="shadow-ray candidate sets (auto = enclosed with fast math, safe with strict)")
-    ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4)")
+    ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4; without the work queue)")
+    ap.add_argument("--work-queue", default="auto", choices=["auto", "on", "off"],
+                    help="wavefront kernel: one launch per step whose waves take (pass, tile) units (PTGPU_OPT_WORK_QUEUE)")
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -116,6 +118,7 @@ def main():
     g = pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
                kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
                math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT, streams=args.streams,
+               work_queue={"auto": 2, "on": 1, "off": 0}[args.work_queue],
                passes_per_launch=args.passes_per_launch,
                shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
                             "auto": pt.CULL_AUTO}[args.cull])
@@ -181,13 +184,18 @@ def main():
         if world == 1 and not args.no_cpu:
             baseline, flops_per_path, ref_flops_per_path, counters = cpu_baseline(
                 args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED}[cull])
-        # One step = args.passes passes.  With S region streams a pass is S concurrent launches of
+        # One step = args.passes passes.  With the work queue a step is ONE launch (rocprof's AverageNs
+        # = avg_step_event_ms).  Without it, with S region streams, a pass is S concurrent launches of
         # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the
         # library's stream (fork/join), so the per-launch figure below is step time / sequential
-        # launch groups, and rocprof's per-launch AverageNs is about S x larger than
-        # avg_launch_group_ms / 1 because the S launches overlap (see DESIGN.md "Measurement").
+        # launch groups (see DESIGN.md "Measurement").
         avg_step_ms = sum(launch_ms) / len(launch_ms)
-        ppl = args.passes_per_launch or (1 if (args.streams > 1 and ((w + 7) // 8) * ((h + 7) // 8) >= 2048) else 8)
+        n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        info = g.scene_info()
+        # the library's own rule (ptgpu.h, PTGPU_OPT_WORK_QUEUE): one launch per step when it applies
+        queue = args.kernel == "wavefront" and (args.work_queue == "on" or (
+            args.work_queue == "auto" and n_tiles >= 2048 and info["primitives"] * (1 + info["lights"]) >= 512))
+        ppl = args.passes if queue else (args.passes_per_launch or (1 if (args.streams > 1 and n_tiles >= 2048) else 8))
         groups_per_step = (args.passes + ppl - 1) // ppl
         # HBM bytes per pass from the committed PMC run of this workload (separate rocprofv3 --pmc
         # passes, profiles/traffic.json); null for any other workload.
@@ -213,7 +221,8 @@ def main():
                         "avg_step_event_ms": avg_step_ms,
                         "avg_launch_group_ms": avg_step_ms / groups_per_step,
                         "launch_groups_per_step": groups_per_step,
-                        "concurrent_launches_per_group": args.streams if ppl == 1 or args.streams > 1 else 1,
+                        "concurrent_launches_per_group": 1 if queue else (args.streams if ppl == 1 or args.streams > 1 else 1),
+                        "work_queue": bool(queue),
                         "passes_per_launch": ppl,
                         "algorithmic_flops_per_path": flops_per_path,
                         "algorithm": f"reference integrator with shadow-ray candidate sets ({cull}); extension rays counted "

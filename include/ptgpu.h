@@ -52,12 +52,14 @@ enum {
                                         triangle clusters (wavefront kernel); 0 = one queue        */
     PTGPU_OPT_BVH = 8,               /* PTGPU_BVH_* (default AUTO)                                  */
     PTGPU_OPT_WORK_QUEUE = 9         /* wavefront kernel: 1 = a render call is ONE launch that fills the
-                                        chip once, its waves taking (pass, tile) units from a queue in
-                                        device memory (no drain between passes; a tile's passes stay in
+                                        chip once, its waves taking units (one tile x 1..16 consecutive
+                                        passes, more where a pass is cheap) from a queue in device
+                                        memory (no drain between passes; a tile's passes stay in
                                         order); 0 = a launch per pass and image region
                                         (PTGPU_OPT_STREAMS); 2 (default) = 1 where a unit is heavy
-                                        enough to pay for its queue traffic (>= 2048 tiles and
-                                        primitives x (1 + lights) >= 512).  Same image either way.   */
+                                        enough to pay for its queue traffic (>= 2048 tiles and passes
+                                        per unit x primitives x (1 + lights) >= 512: cheap scenes need
+                                        several passes per call).  Same image either way.            */
 };
 /* Intersect / IntersectP (geomfunc.h:126-193) scan every object.  For a scene whose cost is that
  * scan over one large mesh the kernels can walk a bounding-volume hierarchy instead (each lane its

@@ -80,10 +80,12 @@ struct PtDeviceParams {
     // dealt round-robin into regions so independent regions can run on concurrent streams
     int tile_first, tile_stride, n_launch_tiles;
     // Work queue of the wavefront kernel (null: one tile per wave, as laid out above).  work[0] = the
-    // next unit, unit = pass * n_tiles + tile (pass-major, so a tile's passes are taken in order);
-    // work[1 + tile] = passes of this launch already stored for the tile; work[1 + n_tiles] = set
-    // when a wave gave up waiting (never, unless a wave died).  Zeroed by the host before the launch.
+    // next unit, unit = chunk * n_tiles + tile, a chunk being unit_passes consecutive passes
+    // (chunk-major, so a tile's passes are taken in order); work[1 + tile] = chunks of this launch
+    // already stored for the tile; work[1 + n_tiles] = set when a wave gave up waiting (never, unless
+    // a wave died).  Zeroed by the host before the launch.
     int *work;
+    int unit_passes;
     // shadow order: always present (the fast build traces every ray in it); smask == nullptr
     // switches the per-light candidate sets off
     const float4 *sprims;

@@ -615,14 +615,22 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     cfg.compute_units = c->compute_units;
     // Work queue (PTGPU_OPT_WORK_QUEUE): one launch for the whole call.  Each unit costs a shared
     // counter increment and an agent-scope release / acquire (microseconds): AUTO takes it where a
-    // unit runs for a good fraction of a millisecond (cornell.txt 398 -> 468, large-object 947 ->
-    // 1 314 Mpaths/s) and not where a pass is cheap (materials.txt 6 129 -> 1 910 with it).
+    // unit can be made to run for a good fraction of a millisecond (cornell.txt 398 -> 468,
+    // large-object 947 -> 1 314 Mpaths/s).
+    // A unit is one tile x `unit_passes` consecutive passes, sized so that it outweighs its queue
+    // traffic (one counter takes ~3e7 increments per second: every scene is capped at 1 920 Mpaths/s
+    // with one-pass units): one pass for cornell.txt, 4 for obj-model, 16 for materials.txt
+    // (6 843 -> 7 526 Mpaths/s with the queue, scripts/queue_units.py).
+    long long unit_passes = work > 0 ? (4096 + work - 1) / work : 16;
+    unit_passes = unit_passes < 1 ? 1 : unit_passes > 16 ? 16 : unit_passes;
+    if (unit_passes > n_passes) unit_passes = n_passes;
     const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
-                       (c->work_queue == 1 || (c->work_queue == 2 && probe.n_tiles >= 2048 && work >= 512));
+                       (c->work_queue == 1 || (c->work_queue == 2 && probe.n_tiles >= 2048 && unit_passes * work >= 512));
     if (queue) {
         PtDeviceParams p = make_params(c, first_sample, n_passes);
         p.bvh_nodes_only = nodes_only && cfg.use_lds;
         p.work = c->d_work;
+        p.unit_passes = (int)unit_passes;
         // the counter and the per-tile words; the give-up word behind them is sticky until it is read
         HIP_TRY(hipMemsetAsync(c->d_work, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
         const int rc = launch(p, c->stream);

@@ -196,7 +196,7 @@ def main():
         work = info["primitives"] * (1 + info["lights"])
         unit_passes = min(max((4096 + work - 1) // max(work, 1), 1), 16, args.passes)
         queue = args.kernel == "wavefront" and (args.work_queue == "on" or (
-            args.work_queue == "auto" and n_tiles >= 2048 and unit_passes * work >= 512))
+            args.work_queue == "auto" and args.integrator == "pt" and n_tiles >= 2048 and unit_passes * work >= 512))
         ppl = args.passes if queue else (args.passes_per_launch or (1 if (args.streams > 1 and n_tiles >= 2048) else 8))
         groups_per_step = (args.passes + ppl - 1) // ppl
         # HBM bytes per pass from the committed PMC run of this workload (separate rocprofv3 --pmc

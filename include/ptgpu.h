@@ -59,7 +59,8 @@ enum {
                                         (PTGPU_OPT_STREAMS); 2 (default) = 1 where a unit is heavy
                                         enough to pay for its queue traffic (>= 2048 tiles and passes
                                         per unit x primitives x (1 + lights) >= 512: cheap scenes need
-                                        several passes per call).  Same image either way.            */
+                                        several passes per call; path-tracing integrator).  The mega
+                                        kernel has no queue.  Same image either way.                 */
 };
 /* Intersect / IntersectP (geomfunc.h:126-193) scan every object.  For a scene whose cost is that
  * scan over one large mesh the kernels can walk a bounding-volume hierarchy instead (each lane its

@@ -624,8 +624,13 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     long long unit_passes = work > 0 ? (4096 + work - 1) / work : 16;
     unit_passes = unit_passes < 1 ? 1 : unit_passes > 16 ? 16 : unit_passes;
     if (unit_passes > n_passes) unit_passes = n_passes;
+    // (Wavefront kernel only; AUTO: under the path-tracing integrator, where the rule above was
+    // measured.  The mega kernel's scenes and the direct-lighting integrator are an order of magnitude
+    // cheaper per pass and run into the counter's rate: a mega kernel with the queue ran caustic at 25
+    // instead of 49 Gpaths/s and cornell dl at 1.8 instead of 3.6.)
     const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
-                       (c->work_queue == 1 || (c->work_queue == 2 && probe.n_tiles >= 2048 && unit_passes * work >= 512));
+                       (c->work_queue == 1 || (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT &&
+                                               probe.n_tiles >= 2048 && unit_passes * work >= 512));
     if (queue) {
         PtDeviceParams p = make_params(c, first_sample, n_passes);
         p.bvh_nodes_only = nodes_only && cfg.use_lds;

@@ -319,6 +319,27 @@ def test_work_queue_is_the_same_image_as_a_launch_per_pass():
         assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all(), math
 
 
+@pytest.mark.parametrize("case", [("materials", pt.KERNEL_WAVEFRONT, 0, 37), ("cornell-large", pt.KERNEL_WAVEFRONT, 0, 20),
+                                  ("obj-model", pt.KERNEL_WAVEFRONT, 1, 3), ("simple", pt.KERNEL_WAVEFRONT, 1, 5)],
+                         ids=lambda c: f"{c[0]}-{KNAME[c[1]]}-{'dl' if c[2] else 'pt'}")
+def test_work_queue_forced_on_is_the_same_image(case):
+    # units of several passes (cheap scenes: up to 16 per unit, a ragged last chunk), a hierarchy, the
+    # direct-lighting integrator, a frame whose last tile row and column are ragged: strict build, every bit
+    name, kernel, integrator, spp = case
+    w, h = 1021, 771
+    sc = pt.LoadedScene(name, w, h)
+    seeds = pt.seed_block(w, h)
+    out = []
+    for q in (0, 1):
+        g = pt.Gpu(0, integrator, kernel=kernel, math=pt.MATH_STRICT, work_queue=q)
+        g.set_scene(sc)
+        g.resize(w, h, seeds)
+        g.render(spp)
+        out.append((g.colors(), g.pixels(), g.seeds()))
+        g.close()
+    assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all()
+
+
 def test_kernels_agree_with_each_other_bitwise():
     # the wavefront restructuring keeps every path's draw order and summation order, so without
     # contraction (strict build) the two kernels agree to the bit; the fast builds contract

@@ -167,6 +167,10 @@ float as_float(int v) {
     return f;
 }
 
+#ifndef PT_QUEUE_MAX_UNITS
+#define PT_QUEUE_MAX_UNITS (1ll << 30)
+#endif
+constexpr long long kQueueMaxUnits = PT_QUEUE_MAX_UNITS; // units of one work-queue launch (an int in the kernel)
 constexpr double kEnclosedMargin = 1e-5; // "inside a sphere" = closer to its centre than r (1 - margin)
 PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     PtDeviceParams p{};
@@ -632,15 +636,22 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
                        (c->work_queue == 1 || (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT &&
                                                probe.n_tiles >= 2048 && unit_passes * work >= 512));
     if (queue) {
-        PtDeviceParams p = make_params(c, first_sample, n_passes);
-        p.bvh_nodes_only = nodes_only && cfg.use_lds;
-        p.work = c->d_work;
-        p.unit_passes = (int)unit_passes;
-        // the counter and the per-tile words; the give-up word behind them is sticky until it is read
-        HIP_TRY(hipMemsetAsync(c->d_work, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
-        const int rc = launch(p, c->stream);
-        if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-        c->queue_in_flight = true;
+        // The kernel numbers its units with an int: a call of more than kQueueMaxUnits units (4K frame,
+        // some 8 000 one-pass chunks) is issued as several launches, in order on the stream.
+        const long long chunks_per_launch = kQueueMaxUnits / probe.n_tiles > 0 ? kQueueMaxUnits / probe.n_tiles : 1;
+        const long long passes_per_launch = chunks_per_launch * unit_passes;
+        for (long long done = 0; done < n_passes; done += passes_per_launch) {
+            const int n = (int)(n_passes - done < passes_per_launch ? n_passes - done : passes_per_launch);
+            PtDeviceParams p = make_params(c, first_sample + (int)done, n);
+            p.bvh_nodes_only = nodes_only && cfg.use_lds;
+            p.work = c->d_work;
+            p.unit_passes = (int)unit_passes;
+            // the counter and the per-tile words; the give-up word behind them is sticky until it is read
+            HIP_TRY(hipMemsetAsync(c->d_work, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
+            const int rc = launch(p, c->stream);
+            if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
+            c->queue_in_flight = true;
+        }
         return PTGPU_OK;
     }
     int launch_error = 0;

@@ -86,8 +86,8 @@ def main():
     ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
-    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "auto"],
-                    help="shadow-ray candidate sets (auto = enclosed with fast math, safe with strict)")
+    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "ball", "auto"],
+                    help="shadow-ray candidate sets (auto = enclosed with fast math, safe with strict; ball is opt-in)")
     ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4; without the work queue)")
     ap.add_argument("--work-queue", default="auto", choices=["auto", "on", "off"],
                     help="wavefront kernel: one launch per step whose waves take (pass, tile) units (PTGPU_OPT_WORK_QUEUE)")
@@ -121,7 +121,7 @@ def main():
                work_queue={"auto": 2, "on": 1, "off": 0}[args.work_queue],
                passes_per_launch=args.passes_per_launch,
                shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
-                            "auto": pt.CULL_AUTO}[args.cull])
+                            "ball": pt.CULL_BALL, "auto": pt.CULL_AUTO}[args.cull])
     cull = args.cull if args.cull != "auto" else ("enclosed" if args.math == "fast" else "safe")
     g.set_scene(sc)
     g.resize(w, h, seeds)
@@ -183,7 +183,8 @@ def main():
         baseline, flops_per_path, ref_flops_per_path, counters = (None, None, None, None)
         if world == 1 and not args.no_cpu:
             baseline, flops_per_path, ref_flops_per_path, counters = cpu_baseline(
-                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED}[cull])
+                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
+                             "ball": pt.CULL_BALL}[cull])
         # One step = args.passes passes.  With the work queue a step is ONE launch (rocprof's AverageNs
         # = avg_step_event_ms).  Without it, with S region streams, a pass is S concurrent launches of
         # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the

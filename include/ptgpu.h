@@ -102,9 +102,22 @@ enum {
  *         1e-4 of cornell.txt's radiance, scripts/wall_sphere_shadow.py) - rounding-level, like
  *         TIGHT's grazing rays.  The library checks at every launch that the camera is inside
  *         every sphere this rule dropped, and renders with the TIGHT sets when it is not.
+ *   BALL  (opt-in) ENCLOSED, and where such a sphere (one that encloses some light) is still in the
+ *         set of a triangle light that reaches out of it, its ray test is replaced by a test of
+ *         one point: the ray starts inside the ball, so it crosses the sphere before maxt exactly
+ *         when its point at maxt lies outside (|o + maxt d - centre|^2 > r^2).  cornell.txt: the
+ *         floor, for the 64 light triangles of the cylinder that reach below it; no shadow ray
+ *         tests a sphere any more.  No faster by itself (464 against 466 Mpaths/s: the sphere loop of
+ *         the far scan costs by being compiled in, not by running - a build without it runs at 493);
+ *         it is the groundwork for a kernel instance without that loop.
+ *         Exact in real arithmetic, but it also removes
+ *         the acne of those grazing rays, which is larger than ENCLOSED's: +5e-4 of cornell.txt's
+ *         radiance against the reference (tests/test_shadow_cull.py) - hence not the default.
+ *         Same per-launch camera check.  Scenes of up to 32 spheres; ENCLOSED otherwise.
  *   AUTO  = SAFE under PTGPU_MATH_STRICT, ENCLOSED under PTGPU_MATH_FAST. */
 enum {
-    PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3, PTGPU_CULL_ENCLOSED = 4
+    PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3, PTGPU_CULL_ENCLOSED = 4,
+    PTGPU_CULL_BALL = 5
 };
 enum {
     PTGPU_MATH_FAST   = 0, /* FMA contraction on, v_rcp/v_rsq/v_sqrt/v_sin/v_cos f32 approximations:
@@ -201,10 +214,11 @@ int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 
 /* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
  * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
- * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT or ENCLOSED (OFF: all
- * ones; ENCLOSED as if the camera were inside every sphere the rule drops),
+ * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT, ENCLOSED or BALL (OFF:
+ * all ones; ENCLOSED and BALL as if the camera were inside every sphere the rule relies on),
  * keep[l * object_count + i] = 1 when object i is scanned for a shadow ray towards the l-th light
- * (sampling order), 0 when it is culled or is not a sphere/triangle.  *n_lights receives the number
+ * (sampling order), 0 when it is culled or is not a sphere/triangle, 2 (BALL) when sphere i is
+ * tested by the ray's point at maxt instead of the ray.  *n_lights receives the number
  * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the
  * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves. */
 int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count,

@@ -68,7 +68,8 @@ void oracle_render_pass_counted(const pt_object *objects, uint32_t n, uint32_t l
 
 /* Replays the product's shadow-ray culling in the restatement (NOT part of the reference; NULL,
  * the default, is the reference's full scan): keep[l * n + i] = 0 makes the any-hit scan of a
- * shadow ray towards the l-th light skip object i.  The matrix comes from
+ * shadow ray towards the l-th light skip object i; 2 (PTGPU_CULL_BALL, spheres only) replaces the
+ * ray test of object i by "the ray's point at maxt lies outside the sphere".  The matrix comes from
  * ptgpu_shadow_candidates (include/ptgpu.h) with the same objects and light count as the renders
  * that follow; the caller keeps it alive until it is reset.  Used to prove on the CPU that a cull
  * mode leaves every bit of the image alone, and to count the tests the culled algorithm performs. */

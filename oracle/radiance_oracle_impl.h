@@ -80,13 +80,22 @@ static int FN(closest_hit)(const pt_object *objects, uint32_t n, const pt_ray *r
 
 /* geomfunc.h:162-193: any hit closer than maxt, early out in index order.
  * `candidates` (NULL upstream) replays the product's shadow-ray culling on the CPU: objects whose
- * byte is 0 are skipped (oracle_set_shadow_candidates). */
+ * byte is 0 are skipped, objects whose byte is 2 (spheres the ray starts inside of) are tested with
+ * the ray's point at maxt instead of the ray (oracle_set_shadow_candidates). */
 static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
                        float maxt, const uint8_t *candidates CTR_PARAM) {
     TALLY(shadow_rays);
     for (uint32_t i = 0; i < n; i++) {
         float dist;
         if (candidates && !candidates[i]) continue;
+        if (candidates && candidates[i] == 2) {
+            /* PTGPU_CULL_BALL replay: the ray starts inside this sphere, so it crosses it before
+             * maxt exactly when its point at maxt lies outside (no ray test) */
+            const v3 end = v3_add(ray->o, v3_scale(maxt, ray->d));
+            const v3 off = v3_sub(end, objects[i].center);
+            if (v3_dot(off, off) > objects[i].radius * objects[i].radius) return 1;
+            continue;
+        }
         if (objects[i].type == PT_SPHERE)
             dist = FN(hit_sphere)(&objects[i], ray CTR_ARG);
         else if (objects[i].type == PT_TRIANGLE)

@@ -15,7 +15,8 @@
 //                          s1 = (color.xyz, sigma)  s2 = (kd.xyz, A)  s3 = (B, 0, 0, 0)
 //   lights [5 * n_lights]  the first min(lightCount, #emissive) emissive primitives, index order:
 //                          l0 = (p1 | center, type)  l1 = (e1 | radius,0,0; w = bit c set when cluster c has a
-//                          group in the light's TIGHT set)  l2 = (e2)  l3 = (emission.xyz, area)
+//                          group in the light's TIGHT set)  l2 = (e2; w = bit g set when sphere group g is tested by the
+//                          ray's end point under PTGPU_CULL_BALL)  l3 = (emission.xyz, area)
 //                          l4 = (unit normal of e1 x e2, plane offset n.p1 lowered by a tolerance) for
 //                               triangle lights; (0,0,0,-1) for spheres and degenerate triangles.
 //                               A point x with n.x < l4.w is behind the light: every sample of the
@@ -86,6 +87,9 @@ struct PtDeviceParams {
     // a wave died).  Zeroed by the host before the launch.
     int *work;
     int unit_passes;
+    // PTGPU_CULL_BALL: the sphere groups (shadow order, first 32) that some light tests by the ray's
+    // point at maxt instead of the ray - which lights, the light record says (l2.w); 0 = no such test
+    unsigned ball_groups;
     // shadow order: always present (the fast build traces every ray in it); smask == nullptr
     // switches the per-light candidate sets off
     const float4 *sprims;

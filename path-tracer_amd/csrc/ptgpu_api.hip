@@ -72,7 +72,8 @@ struct ptgpu_ctx {
     int4 *d_segs = nullptr;
     // shadow-ray tables (device_params.h); null when the scene gains nothing from them
     float4 *d_sprims = nullptr, *d_sprims_planes = nullptr, *d_sshade = nullptr;
-    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_smask_enclosed = nullptr, *d_cmask = nullptr;
+    unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_smask_enclosed = nullptr, *d_smask_ball = nullptr, *d_cmask = nullptr;
+    unsigned ball_groups = 0;   // sphere groups some light tests by the ray's end point (PTGPU_CULL_BALL)
     std::vector<float4> enclosing; // (centre, radius) of the spheres PTGPU_CULL_ENCLOSED took out of a set
     float4 *d_cbounds = nullptr;
     // BVH (device_params.h): one block + the id tables in each build's numbering
@@ -136,9 +137,10 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_smask_safe) (void)hipFree(c->d_smask_safe);
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     if (c->d_smask_enclosed) (void)hipFree(c->d_smask_enclosed);
+    if (c->d_smask_ball) (void)hipFree(c->d_smask_ball);
     c->d_sprims = nullptr;
     c->d_sprims_planes = nullptr;
-    c->d_smask_safe = c->d_smask_tight = c->d_smask_enclosed = nullptr;
+    c->d_smask_safe = c->d_smask_tight = c->d_smask_enclosed = c->d_smask_ball = nullptr;
     c->d_prims = c->d_shade = c->d_lights = nullptr;
     c->d_segs = nullptr;
     c->have_scene = false;
@@ -208,7 +210,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.n_launch_tiles = p.n_tiles;
     int cull = c->shadow_cull;
     if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_ENCLOSED;
-    if (cull == PTGPU_CULL_ENCLOSED) {
+    if (cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) {
         // the rule holds for paths that start inside every sphere it dropped: camera rays leave from
         // orig + 0.1 rdir (main-cpu.c:76), |rdir| < 3 for any sane field of view, so one unit of margin
         for (const float4 &s : c->enclosing) {
@@ -221,14 +223,16 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     p.smask = cull == PTGPU_CULL_SAFE       ? c->d_smask_safe
               : cull == PTGPU_CULL_TIGHT    ? c->d_smask_tight
               : cull == PTGPU_CULL_ENCLOSED ? c->d_smask_enclosed
+              : cull == PTGPU_CULL_BALL     ? c->d_smask_ball
                                             : nullptr;
+    p.ball_groups = cull == PTGPU_CULL_BALL && p.smask ? c->ball_groups : 0u;
     p.n_sph_real = (int)c->info.spheres;
     p.sg_sph = c->sg_sph;
     p.sg_tri = c->sg_tri;
     p.mw_sph = c->mw_sph;
     p.mw_tri = c->mw_tri;
     // ray binning on triangle clusters: fast build, TIGHT sets only (the bins are built from them)
-    const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED) && p.smask &&
+    const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) && p.smask &&
                       c->math == PTGPU_MATH_FAST;
     p.n_clusters = bins ? c->n_clusters : 0;
     p.cmask = c->d_cmask;
@@ -238,6 +242,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     if (c->math == PTGPU_MATH_FAST && !use_bvh) p.sprims = c->d_sprims_planes;
     if (use_bvh) { // the hierarchy replaces the candidate sets
         p.smask = nullptr;
+        p.ball_groups = 0;
         p.n_clusters = 0;
         p.bvh = c->d_bvh;
         const bool strict = c->math == PTGPU_MATH_STRICT;
@@ -264,7 +269,8 @@ struct ShadowTables {
     std::vector<unsigned long long> cluster_masks;   // (1 + clusters) x mw_tri words
     std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
     std::vector<float4> hyb_nodes;                   // hierarchy whose leaves are the triangle groups
-    std::vector<unsigned long long> safe, tight, enclosed;
+    std::vector<unsigned long long> safe, tight, enclosed, ball;
+    std::vector<unsigned> light_ball;                // per light: sphere groups tested by the ray's end point (BALL)
     std::vector<float4> enclosing;                   // spheres ENCLOSED dropped from at least one set
     bool tables_built = false;
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
@@ -280,7 +286,8 @@ D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x
 double len(D3 a) { return std::sqrt(dot(a, a)); }
 
 // keep[l * n_prims + i] = primitive i may occlude a shadow ray towards light l under `mode`
-// (PTGPU_CULL_SAFE / TIGHT / ENCLOSED, ptgpu.h; anything else keeps everything).
+// (PTGPU_CULL_SAFE / TIGHT / ENCLOSED / BALL, ptgpu.h; anything else keeps everything); under BALL
+// 2 = it may, and the test is whether the ray's point at maxt lies outside sphere i.
 // prims: 3 quads per primitive in index order; types[i]: PT_SPHERE / PT_TRIANGLE; lights: 4 quads each;
 // dielectric[i]: primitive i refracts (paths pass through it: it encloses nothing).
 std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const std::vector<int> &types,
@@ -288,9 +295,12 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
                                        int mode) {
     const size_t n_prims = types.size(), n_lights = lights.size() / 4;
     std::vector<uint8_t> keep(n_lights * n_prims, 1);
-    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED) return keep;
-    const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED;
+    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED && mode != PTGPU_CULL_BALL)
+        return keep;
+    const bool ball_rule = mode == PTGPU_CULL_BALL;
+    const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED || ball_rule;
     if (enclosed_rule) mode = PTGPU_CULL_TIGHT;
+    std::vector<uint8_t> encloses(n_prims, 0), ruled(n_lights, 0); // sphere i encloses some light; light l has sets
     const double eps = (double)PT_EPSILON;
     for (size_t l = 0; l < n_lights; ++l) {
         int light_type;
@@ -300,6 +310,7 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
         const double nn = len(n), size = len(e1) + len(e2);
         // one-sided triangle lights with a usable normal; every other light keeps every primitive
         if (light_type != PT_TRIANGLE || !std::isfinite(nn) || !(nn > 1e-12 * size * size)) continue;
+        ruled[l] = 1;
         n = {n.x / nn, n.y / nn, n.z / nn};
         // `h` = height of a point of the primitive above the light's plane, `reach` = its distance
         // from the light.  A NaN makes the comparison false: kept.
@@ -315,7 +326,10 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
                 // ENCLOSED: the light's three corners strictly inside an opaque sphere (a NaN keeps it)
                 if (enclosed_rule && !dielectric[i]) {
                     const double inside = r * (1 - kEnclosedMargin);
-                    if (len(c) <= inside && len(sub(c, e1)) <= inside && len(sub(c, e2)) <= inside) all_behind = true;
+                    if (len(c) <= inside && len(sub(c, e1)) <= inside && len(sub(c, e2)) <= inside) {
+                        if (!all_behind) encloses[i] = 1; // what make_params checks the camera against
+                        all_behind = true;
+                    }
                 }
             } else {
                 const D3 a = sub(d3(prims[3 * i]), p0);
@@ -325,6 +339,16 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
             if (all_behind) keep[l * n_prims + i] = 0;
         }
     }
+    // BALL: a shadow ray of a path that lives inside an opaque sphere (the spheres ENCLOSED relies
+    // on) crosses the sphere before maxt exactly when its point at maxt is outside it: where such a
+    // sphere is still in a light's set, 2 = "test that point, not the ray".
+    // (The device keeps a light's point-tested spheres in a 32-bit word: scenes of up to 32 spheres.)
+    size_t n_spheres = 0;
+    for (size_t i = 0; i < n_prims; ++i) n_spheres += types[i] == PT_SPHERE;
+    if (ball_rule && n_spheres <= 32)
+        for (size_t l = 0; l < n_lights; ++l)
+            for (size_t i = 0; i < n_prims; ++i)
+                if (ruled[l] && encloses[i] && keep[l * n_prims + i]) keep[l * n_prims + i] = 2;
     return keep;
 }
 
@@ -491,10 +515,13 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
                                               ? keep_enclosed
                                               : shadow_candidates(prims, types, lights, dielectric, mode);
         out.assign(n_lights * words, 0ull);
+        if (mode == PTGPU_CULL_BALL) t.light_ball.assign(n_lights, 0u);
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
             for (size_t k = 0; k < sph_slots.size(); ++k)
-                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]])
+                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]] == 2)
+                    t.light_ball[l] |= 1u << (k / kSphereGroup); // at most 32 spheres (shadow_candidates)
+                else if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]])
                     out[l * words + (k / kSphereGroup) / 64] |= 1ull << ((k / kSphereGroup) % 64);
             for (size_t k = 0; k < tri_slots.size(); ++k)
                 if (tri_slots[k] >= 0 && keep[l * n_prims + tri_slots[k]])
@@ -509,11 +536,14 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     if (!t.tables_built) {
         t.mean_safe = t.mean_tight = t.mean_enclosed = (double)n_prims;
         t.light_clusters.assign(n_lights, 0u);
+        t.light_ball.assign(n_lights, 0u);
         return;
     }
     masks(PTGPU_CULL_SAFE, t.safe, t.mean_safe);
     masks(PTGPU_CULL_TIGHT, t.tight, t.mean_tight);
     masks(PTGPU_CULL_ENCLOSED, t.enclosed, t.mean_enclosed);
+    double mean_ball;
+    masks(PTGPU_CULL_BALL, t.ball, mean_ball);
     {
         const std::vector<uint8_t> tight = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_TIGHT);
         for (size_t i = 0; i < n_prims; ++i) {
@@ -780,7 +810,7 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         ctx->waves_per_group = value;
         return PTGPU_OK;
     case PTGPU_OPT_SHADOW_CULL:
-        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_ENCLOSED)
+        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_BALL)
             return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
         ctx->shadow_cull = value;
         return PTGPU_OK;
@@ -872,6 +902,11 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     if (info.lights >= (1u << 18)) st.cluster_bounds.clear(); // the near-queue tag holds 18 bits of light index
     for (size_t l = 0; l < st.light_clusters.size(); ++l)   // l1.w is free in both light kinds
         dlights[kLightQuads * l + 1].w = as_float(st.cluster_bounds.empty() ? 0 : (int)st.light_clusters[l]);
+    ctx->ball_groups = 0;
+    for (size_t l = 0; l < st.light_ball.size(); ++l) { // l2.w is free in both light kinds
+        dlights[kLightQuads * l + 2].w = as_float((int)st.light_ball[l]);
+        ctx->ball_groups |= st.light_ball[l];
+    }
     std::vector<float4> sshade;
     for (int slot : st.prim_of_slot)
         for (int q = 0; q < 4; ++q) sshade.push_back(slot >= 0 ? shade[4 * slot + q] : make_float4(0.f, 0.f, 0.f, 0.f));
@@ -940,6 +975,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));
         HIP_TRY(upload(ctx->d_smask_tight, st.tight));
         HIP_TRY(upload(ctx->d_smask_enclosed, st.enclosed));
+        HIP_TRY(upload(ctx->d_smask_ball, st.ball));
         ctx->enclosing = st.enclosing;
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
         HIP_TRY(upload(ctx->d_cbounds, st.cluster_bounds));
@@ -982,8 +1018,9 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
 int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count, int mode,
                             uint8_t *keep, uint32_t *n_lights) {
     if (!objects || !n_lights) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: null argument");
-    if (mode != PTGPU_CULL_OFF && mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED)
-        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE, TIGHT or ENCLOSED");
+    if (mode != PTGPU_CULL_OFF && mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED &&
+        mode != PTGPU_CULL_BALL)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE, TIGHT, ENCLOSED or BALL");
     PackedScene geo;
     pack_geometry(objects, object_count, light_count, geo);
     *n_lights = (uint32_t)(geo.lights.size() / 4);

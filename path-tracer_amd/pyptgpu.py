@@ -223,7 +223,7 @@ OPT_RAY_BINS = 7
 OPT_BVH = 8
 OPT_WORK_QUEUE = 9
 BVH_OFF, BVH_ON, BVH_AUTO = 0, 1, 2
-CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED = 0, 1, 2, 3, 4
+CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED, CULL_BALL = 0, 1, 2, 3, 4, 5
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1

@@ -196,6 +196,52 @@ def test_shadow_cull_enclosed_equals_its_cpu_replay_and_falls_back_outside(kerne
     assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all()
 
 
+@pytest.mark.parametrize("lds", [1, 0])
+@pytest.mark.parametrize("kernel", [pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT], ids=["mega", "wavefront"])
+def test_shadow_cull_ball_equals_its_cpu_replay_and_falls_back_outside(kernel, lds):
+    # BALL (opt-in): the floor of cornell.txt is tested by the shadow ray's end point for the lights
+    # that reach below it.  A fixed algorithm: strict build == oracle replay, bit for bit.
+    name, w, h, spp = "cornell", 96, 72, 3
+    sc = pt.LoadedScene(name, w, h)
+    keep = pt.shadow_candidates(sc, pt.CULL_BALL)
+    assert (keep == 2).sum() > 30
+    with ob.shadow_candidates(keep):
+        cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_BALL, lds=lds)
+    assert (sd == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all()
+    enclosed = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_ENCLOSED, lds=lds)
+    assert not same_bits(colors, enclosed[0])                  # the mode does something
+    # a camera outside the walls: TIGHT sets, no point tests
+    out = []
+    for cull in (pt.CULL_BALL, pt.CULL_TIGHT):
+        g = pt.Gpu(0, 0, kernel=kernel, math=pt.MATH_STRICT, shadow_cull=cull, lds=lds)
+        g.set_scene(sc)
+        cam = pt.Camera.from_buffer_copy(sc.camera)
+        cam.orig.z = 400.0                                     # beyond the front wall (z = 270)
+        g.set_camera(cam)
+        g.resize(w, h, pt.seed_block(w, h))
+        g.render(2)
+        out.append((g.colors(), g.seeds()))
+        g.close()
+    assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all()
+
+
+def test_shadow_cull_ball_fast_build_full_size():
+    # fast build, 1024x768: BALL against ENCLOSED - the same draws, a slightly brighter floor
+    # (the acne of the grazing rays is gone), nothing else
+    w, h, spp = 1024, 768, 4
+    enc = gpu_render("cornell", w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, cull=pt.CULL_ENCLOSED)
+    ball = gpu_render("cornell", w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, cull=pt.CULL_BALL)
+    assert (enc[2] == ball[2]).all()
+    ok = ~np.isnan(enc[0]).any(1) & ~np.isnan(ball[0]).any(1)
+    d = ball[0][ok].astype(np.float64) - enc[0][ok]
+    mean = float(enc[0][ok].mean(dtype=np.float64))
+    print(f"BALL vs ENCLOSED, fast, {w}x{h}x{spp}: mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} "
+          f"of the radiance, {(d.min(1) < -1e-5).mean():.2e} of the pixels darker")
+    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean
+    assert (d.min(1) < -1e-5).mean() <= 2e-2
+
+
 def test_shadow_cull_full_size_cornell_safe_is_brute_force():
     # 1024x768 x 4 passes: ~8e8 shadow rays; SAFE and OFF must agree in every bit (NaN pixels included)
     w, h, spp = 1024, 768, 4
@@ -242,7 +288,7 @@ def test_scene_info_reports_shadow_tables_and_clusters():
     g.set_scene(pt.LoadedScene("obj-model", 32, 24))                        # nothing to cull: no tables, no bins
     info = g.scene_info()
     assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 322
-    for opt, bad in ((pt.OPT_SHADOW_CULL, 5), (pt.OPT_SHADOW_CULL, -1), (pt.OPT_WORK_QUEUE, 3), (10, 0)):
+    for opt, bad in ((pt.OPT_SHADOW_CULL, 6), (pt.OPT_SHADOW_CULL, -1), (pt.OPT_WORK_QUEUE, 3), (10, 0)):
         with pytest.raises(pt.GpuError):
             g.set_option(opt, bad)
     g.close()

@@ -159,3 +159,54 @@ def test_enclosed_replay_moves_cornell_by_its_acne_only():
           f"mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} of the radiance")
     assert (d >= -1e-6).all()                                   # only occlusions are lost: nothing gets darker
     assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean
+
+
+def test_ball_marks_the_enclosing_spheres_a_light_reaches_out_of():
+    sc = pt.LoadedScene("cornell", 32, 24)
+    o, real, lights = geometry(sc)
+    enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
+    ball = pt.shadow_candidates(sc, pt.CULL_BALL)
+    assert ((ball != 0) == (enc != 0)).all()                    # the same pairs, some tested another way
+    marked = np.argwhere(ball == 2)
+    walls = np.nonzero((o["type"] == 0) & (o["radius"] >= 1000))[0]
+    floor = [i for i in walls if o["center"][i][1] > 9000][0]
+    # cornell: the floor, for every light of the cylinder that still had it
+    assert len(marked) > 30 and (marked[:, 1] == floor).all() and (ball[:, floor] != 1).all()
+    for l, i in marked:
+        c, r = o["center"][i].astype(np.float64), float(o["radius"][i])
+        inside = [np.linalg.norm(v.astype(np.float64) - c) <= r * (1 - 1e-5) for v in (o["p1"][lights[l]], o["p2"][lights[l]], o["p3"][lights[l]])]
+        assert not all(inside)                                  # a light wholly inside is dropped, not marked
+    # a sphere that encloses no light (the small ones of materials.txt) is never marked, sphere lights
+    # mark nothing, and a scene of more than 32 spheres falls back to ENCLOSED
+    for name in ("materials", "simple", "complex"):
+        s2 = pt.LoadedScene(name, 32, 24)
+        b2, e2 = pt.shadow_candidates(s2, pt.CULL_BALL), pt.shadow_candidates(s2, pt.CULL_ENCLOSED)
+        o2 = s2.objects
+        for l, i in np.argwhere(b2 == 2):
+            assert o2["type"][i] == 0 and o2["material_id"][i] != 2 and (e2[:, i] == 0).any()
+        if name == "complex":
+            assert (b2 == e2).all()
+    sc.objects["material_id"][walls] = 2                        # glass walls enclose nothing
+    assert (pt.shadow_candidates(sc, pt.CULL_BALL) == pt.shadow_candidates(sc, pt.CULL_TIGHT)).all()
+
+
+def test_ball_replay_moves_cornell_by_its_acne_only():
+    w, h, spp = 96, 72, 6
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_ENCLOSED)):
+        enc = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_BALL)):
+        ball = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    assert (enc.seeds == ball.seeds).all()                      # draws never depend on a shadow test
+    ok = ~(np.isnan(enc.colors).any(1) | np.isnan(ball.colors).any(1))
+    d = ball.colors[ok].astype(np.float64) - enc.colors[ok]
+    mean = float(enc.colors[ok].mean())
+    print(f"BALL vs ENCLOSED on the CPU: {(np.abs(d).max(1) > 0).mean():.3f} of the pixels differ, "
+          f"mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} of the radiance, "
+          f"{(d.min(1) < -1e-6).mean():.2e} of the pixels darker")
+    # the floor's self-shadowing acne of the grazing rays towards the foot of the cylinder goes
+    # (brighter: +5e-4, more than ENCLOSED's, which is why BALL is opt-in); a ray end within
+    # rounding of the floor's surface may be classed either way (0.5 % of the pixels get darker)
+    assert (d.min(1) < -1e-6).mean() <= 1e-2
+    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean

@@ -107,13 +107,12 @@ enum {
  *         one point: the ray starts inside the ball, so it crosses the sphere before maxt exactly
  *         when its point at maxt lies outside (|o + maxt d - centre|^2 > r^2).  cornell.txt: the
  *         floor, for the 64 light triangles of the cylinder that reach below it; no shadow ray
- *         tests a sphere any more.  No faster by itself (464 against 466 Mpaths/s: the sphere loop of
- *         the far scan costs by being compiled in, not by running - a build without it runs at 493);
- *         it is the groundwork for a kernel instance without that loop.
- *         Exact in real arithmetic, but it also removes
+ *         tests a sphere any more and most batches of shadow rays have nothing left to scan
+ *         (467 -> 494 Mpaths/s).  Exact in real arithmetic, but it also removes
  *         the acne of those grazing rays, which is larger than ENCLOSED's: +5e-4 of cornell.txt's
  *         radiance against the reference (tests/test_shadow_cull.py) - hence not the default.
- *         Same per-launch camera check.  Scenes of up to 32 spheres; ENCLOSED otherwise.
+ *         Same per-launch camera check.  Scenes of up to 32 spheres whose lights are all
+ *         one-sided triangles; ENCLOSED otherwise.
  *   AUTO  = SAFE under PTGPU_MATH_STRICT, ENCLOSED under PTGPU_MATH_FAST. */
 enum {
     PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3, PTGPU_CULL_ENCLOSED = 4,

@@ -342,10 +342,13 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
     // BALL: a shadow ray of a path that lives inside an opaque sphere (the spheres ENCLOSED relies
     // on) crosses the sphere before maxt exactly when its point at maxt is outside it: where such a
     // sphere is still in a light's set, 2 = "test that point, not the ray".
-    // (The device keeps a light's point-tested spheres in a 32-bit word: scenes of up to 32 spheres.)
+    // (The device keeps a light's point-tested spheres in a 32-bit word, and one scene-wide word of
+    // spheres that leave the ray scans: scenes of up to 32 spheres whose lights all have sets.)
     size_t n_spheres = 0;
     for (size_t i = 0; i < n_prims; ++i) n_spheres += types[i] == PT_SPHERE;
-    if (ball_rule && n_spheres <= 32)
+    bool all_ruled = true; // a set bit of such a sphere then means the point test for every light
+    for (size_t l = 0; l < n_lights; ++l) all_ruled = all_ruled && ruled[l];
+    if (ball_rule && n_spheres <= 32 && all_ruled)
         for (size_t l = 0; l < n_lights; ++l)
             for (size_t i = 0; i < n_prims; ++i)
                 if (ruled[l] && encloses[i] && keep[l * n_prims + i]) keep[l * n_prims + i] = 2;
@@ -519,10 +522,11 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
             for (size_t k = 0; k < sph_slots.size(); ++k)
-                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]] == 2)
-                    t.light_ball[l] |= 1u << (k / kSphereGroup); // at most 32 spheres (shadow_candidates)
-                else if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]])
+                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]]) {
                     out[l * words + (k / kSphereGroup) / 64] |= 1ull << ((k / kSphereGroup) % 64);
+                    if (keep[l * n_prims + sph_slots[k]] == 2) // at most 32 spheres (shadow_candidates)
+                        t.light_ball[l] |= 1u << (k / kSphereGroup);
+                }
             for (size_t k = 0; k < tri_slots.size(); ++k)
                 if (tri_slots[k] >= 0 && keep[l * n_prims + tri_slots[k]])
                     out[l * words + t.mw_sph + (k / kTriGroup) / 64] |= 1ull << ((k / kTriGroup) % 64);

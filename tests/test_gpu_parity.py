@@ -238,7 +238,9 @@ def test_shadow_cull_ball_fast_build_full_size():
     mean = float(enc[0][ok].mean(dtype=np.float64))
     print(f"BALL vs ENCLOSED, fast, {w}x{h}x{spp}: mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} "
           f"of the radiance, {(d.min(1) < -1e-5).mean():.2e} of the pixels darker")
-    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean
+    # measured: mean +4.0e-4, rmse 9.6e-3 of the radiance (4 spp: one lost occlusion is a quarter of a
+    # pixel's estimate), 0.3 % of the pixels darker
+    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 2e-2 * mean
     assert (d.min(1) < -1e-5).mean() <= 2e-2
 
 

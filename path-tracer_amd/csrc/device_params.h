@@ -144,3 +144,12 @@ namespace ptk_strict_bvh {
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }
+// PTGPU_CULL_BALL: the hybrid fast build and the strict build with the point test compiled in
+namespace ptk_fast_ball {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+}
+namespace ptk_strict_ball {
+int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+}

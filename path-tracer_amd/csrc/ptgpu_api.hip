@@ -256,6 +256,9 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
         p.hyb_nodes = c->d_hyb_nodes; // candidate sets stay on; extension rays take the hierarchy
         p.n_hnodes = c->n_hnodes;
     }
+    // the fast build's point test lives in the hybrid instance (kernels_fast_ball.hip): without the
+    // hierarchy (PTGPU_OPT_BVH OFF) BALL renders as ENCLOSED - the same sets, the sphere ray-tested
+    if (c->math == PTGPU_MATH_FAST && !p.n_hnodes) p.ball_groups = 0;
     return p;
 }
 
@@ -643,6 +646,11 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
             if (kernel == PTGPU_KERNEL_MEGA)
                 return strict ? ptk_strict_bvh::launch_mega(p, cfg, s) : ptk_fast_bvh::launch_mega(p, cfg, s);
             return strict ? ptk_strict_bvh::launch_wavefront(p, cfg, s) : ptk_fast_bvh::launch_wavefront(p, cfg, s);
+        }
+        if (p.ball_groups) { // PTGPU_CULL_BALL in effect: the instances with the point test (make_params)
+            if (kernel == PTGPU_KERNEL_MEGA)
+                return strict ? ptk_strict_ball::launch_mega(p, cfg, s) : ptk_fast_ball::launch_mega(p, cfg, s);
+            return strict ? ptk_strict_ball::launch_wavefront(p, cfg, s) : ptk_fast_ball::launch_wavefront(p, cfg, s);
         }
         if (p.n_hnodes)
             return kernel == PTGPU_KERNEL_MEGA ? ptk_fast_hyb::launch_mega(p, cfg, s) : ptk_fast_hyb::launch_wavefront(p, cfg, s);

@@ -10,6 +10,6 @@ mkdir -p ../variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wall -Wno-unused-function -fno-slp-vectorize"
 for n in 1 2 3; do
   /opt/rocm/bin/hipcc $F -DPT_ABLATE=$n -ffp-contract=fast-honor-pragmas -DPT_WF_WAVES_PER_SIMD=6 -c kernels_fast_hyb.hip -o ../variants/kf$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libptgpu_ablate$n.so ../variants/kf$n.o kernels_fast.o kernels_strict.o kernels_fast_bvh.o kernels_strict_bvh.o ptgpu_api.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libptgpu_ablate$n.so ../variants/kf$n.o kernels_fast.o kernels_strict.o kernels_fast_bvh.o kernels_strict_bvh.o kernels_fast_ball.o kernels_strict_ball.o ptgpu_api.o
 done
 ls -la ../variants/*.so

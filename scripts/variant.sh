@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../path-tracer_amd/csrc"
 mkdir -p ../variants
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wall -Wno-unused-function -fno-slp-vectorize"
 OBJS=""
-for tu in kernels_fast kernels_strict kernels_fast_bvh kernels_strict_bvh kernels_fast_hyb; do
+for tu in kernels_fast kernels_strict kernels_fast_bvh kernels_strict_bvh kernels_fast_hyb kernels_fast_ball kernels_strict_ball; do
   if [[ " $TUS " == *" $tu "* ]]; then
     C="-ffp-contract=fast-honor-pragmas"; [[ $tu == *strict* ]] && C="-ffp-contract=off"
     /opt/rocm/bin/hipcc $F $FLAGS $C -DPT_WF_WAVES_PER_SIMD=6 -c $tu.hip -o ../variants/${NAME}_$tu.o

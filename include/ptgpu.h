@@ -108,7 +108,7 @@ enum {
  *         when its point at maxt lies outside (|o + maxt d - centre|^2 > r^2).  cornell.txt: the
  *         floor, for the 64 light triangles of the cylinder that reach below it; no shadow ray
  *         tests a sphere any more and most batches of shadow rays have nothing left to scan
- *         (467 -> 494 Mpaths/s).  Exact in real arithmetic, but it also removes
+ *         (474 -> 494 Mpaths/s).  Exact in real arithmetic, but it also removes
  *         the acne of those grazing rays, which is larger than ENCLOSED's: +5e-4 of cornell.txt's
  *         radiance against the reference (tests/test_shadow_cull.py) - hence not the default.
  *         Same per-launch camera check.  Scenes of up to 32 spheres whose lights are all

@@ -55,14 +55,15 @@ int main(int argc, char *argv[]) {
             ++i;
         } else if (!strcmp(a, "--cull") && v) {
             cull = !strcmp(v, "off") ? PTGPU_CULL_OFF : !strcmp(v, "safe") ? PTGPU_CULL_SAFE
-                   : !strcmp(v, "tight") ? PTGPU_CULL_TIGHT : PTGPU_CULL_AUTO;
+                   : !strcmp(v, "tight") ? PTGPU_CULL_TIGHT : !strcmp(v, "enclosed") ? PTGPU_CULL_ENCLOSED
+                   : !strcmp(v, "ball") ? PTGPU_CULL_BALL : PTGPU_CULL_AUTO;
             ++i;
         }
         else if (!strcmp(a, "--quiet")) quiet = 1;
         else if (a[0] == '-' && a[1] == '-') {
             fprintf(stderr, "Usage: %s [<use CPU/GPU device> <workgroup size> <kernel file name> <window width> "
                             "<window height> <scene file>] [--spp N] [--out image.ppm] [--integrator pt|dl] "
-                            "[--math fast|strict] [--kernel auto|wavefront|mega] [--cull auto|off|safe|tight] [--models DIR] "
+                            "[--math fast|strict] [--kernel auto|wavefront|mega] [--cull auto|off|safe|tight|enclosed|ball] [--models DIR] "
                             "[--device N]\n", argv[0]);
             exit(-1);
         } else if (npos < 6) pos[npos++] = a;

@@ -226,6 +226,19 @@ def test_shadow_cull_ball_equals_its_cpu_replay_and_falls_back_outside(kernel, l
     assert same_bits(out[0][0], out[1][0]) and (out[0][1] == out[1][1]).all()
 
 
+def test_shadow_cull_ball_without_the_hierarchy_renders_as_enclosed():
+    # the fast build's point test lives in the hybrid instance: with PTGPU_OPT_BVH OFF the mode keeps
+    # the sets and ray-tests the sphere - the same bits as ENCLOSED
+    a = gpu_render("cornell", 160, 120, 3, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, cull=pt.CULL_BALL, bvh=pt.BVH_OFF)
+    b = gpu_render("cornell", 160, 120, 3, 0, pt.KERNEL_WAVEFRONT, pt.MATH_FAST, cull=pt.CULL_ENCLOSED, bvh=pt.BVH_OFF)
+    assert same_bits(a[0], b[0]) and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    # and a scene the rule does not apply to (sphere lights: no sets at all) is untouched by it
+    for math in (pt.MATH_FAST, pt.MATH_STRICT):
+        a = gpu_render("materials", 96, 64, 3, 0, pt.KERNEL_WAVEFRONT, math, cull=pt.CULL_BALL)
+        b = gpu_render("materials", 96, 64, 3, 0, pt.KERNEL_WAVEFRONT, math, cull=pt.CULL_ENCLOSED)
+        assert same_bits(a[0], b[0]) and (a[2] == b[2]).all()
+
+
 def test_shadow_cull_ball_fast_build_full_size():
     # fast build, 1024x768: BALL against ENCLOSED - the same draws, a slightly brighter floor
     # (the acne of the grazing rays is gone), nothing else

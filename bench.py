@@ -132,7 +132,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
-    colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * w * h),
+    colors_t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), pt.COLOR_STRIDE_FLOATS * w * h),
                                device=torch.device("cuda", local_rank))
 
     def barrier():
@@ -219,7 +219,7 @@ def main():
             achieved = flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12
             roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                        "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE + WRITE_SIZE), algorithmic %d" % (44 * w * h * args.passes),
+                        "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE + WRITE_SIZE), algorithmic %d" % (52 * w * h * args.passes),
                         "kernel": f"radiance_{args.kernel}_kernel ({args.math})",
                         "avg_step_event_ms": avg_step_ms,
                         "avg_launch_group_ms": avg_step_ms / groups_per_step,
@@ -236,7 +236,7 @@ def main():
                         "reference_equivalent_flops_per_path": ref_flops_per_path,
                         "reference_equivalent_tflops": ref_flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12,
                         "paths_per_step": paths_per_launch,
-                        "hbm_algorithmic_bytes_per_pass": 44 * w * h}
+                        "hbm_algorithmic_bytes_per_pass": 52 * w * h}
         line = {
             "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

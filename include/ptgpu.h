@@ -185,9 +185,15 @@ int ptgpu_read_seeds(ptgpu_ctx *ctx, uint32_t *seeds);
 int ptgpu_write_colors(ptgpu_ctx *ctx, const float *colors_xyz);
 
 /* Multi-GPU support (no reference counterpart): the device address of the colour
- * buffer (3*W*H floats) so a caller can all-reduce it in place with RCCL, the stream the library
- * works on, and a re-pack of `pixels` from the (reduced) colour buffer scaled by `scale`
- * (1/ranks after a sum all-reduce of equal-pass running means). */
+ * buffer so a caller can all-reduce it in place with RCCL, the stream the library works on, and a
+ * re-pack of `pixels` from the (reduced) colour buffer scaled by `scale` (1/ranks after a sum
+ * all-reduce of equal-pass running means).
+ * On the device the sample buffer is one float4 per pixel - (r, g, b, 0) at [(H-1-y)*W+x] - so that
+ * the kernels' accumulation is one 16-byte load and one 16-byte store per lane (the reference keeps
+ * 3 floats per pixel, path-tracing.cl:87-111; ptgpu_read_colors / ptgpu_write_colors convert): the
+ * buffer behind ptgpu_colors_device_ptr is PTGPU_COLOR_STRIDE_FLOATS * W * H floats, and a sum over
+ * all of them leaves the spare channel 0. */
+#define PTGPU_COLOR_STRIDE_FLOATS 4
 int ptgpu_colors_device_ptr(ptgpu_ctx *ctx, void **device_ptr);
 int ptgpu_stream(ptgpu_ctx *ctx, void **hip_stream);
 int ptgpu_scale_and_repack(ptgpu_ctx *ctx, float scale);

@@ -72,19 +72,19 @@ struct PtDeviceParams {
     int width, height;
     int current_sample;   // sample index of the first pass of this launch
     int n_passes;         // passes done inside this launch (wavefront kernel keeps state in registers)
-    float    *colors;     // 3 floats per pixel at (H-1-y)*W+x
+    float4   *colors;     // (r, g, b, 0) per pixel at (H-1-y)*W+x: one 16-byte access per lane
     uint32_t *pixels;     // y*W+x
-    uint32_t *seeds;      // 2 words per pixel at y*W+x
+    uint2    *seeds;      // the two generator words of the pixel at y*W+x: one 8-byte access
     int tiles_x;          // image width in 8x8 pixel tiles (one wave = one tile)
     int n_tiles;
     // this launch covers tiles tile_first + k * tile_stride, k in [0, n_launch_tiles): the image is
     // dealt round-robin into regions so independent regions can run on concurrent streams
     int tile_first, tile_stride, n_launch_tiles;
-    // Work queue of the wavefront kernel (null: one tile per wave, as laid out above).  work[0] = the
+    // Work queue of the wavefront kernel (null: one tile per wave, as laid out above).  work[1] = the
     // next unit, unit = chunk * n_tiles + tile, a chunk being unit_passes consecutive passes
-    // (chunk-major, so a tile's passes are taken in order); work[1 + tile] = chunks of this launch
-    // already stored for the tile; work[1 + n_tiles] = set when a wave gave up waiting (never, unless
-    // a wave died).  Zeroed by the host before the launch.
+    // (chunk-major, so a tile's passes are taken in order); work[2 + tile] = chunks of this launch
+    // already stored for the tile; both zeroed by the host before the launch.  work[0] = set when a
+    // wave gave up waiting (never, unless a wave died); sticky until the host has read it.
     int *work;
     int unit_passes;
     // PTGPU_CULL_BALL: the sphere groups (shadow order, first 32) that some light tests by the ray's

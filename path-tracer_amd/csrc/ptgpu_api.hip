@@ -12,6 +12,7 @@
 #include <cmath>
 #include <map>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "bvh_build.h"
@@ -95,11 +96,15 @@ struct ptgpu_ctx {
 
     // image
     int width = 0, height = 0;
-    float *d_colors = nullptr;
-    uint32_t *d_pixels = nullptr, *d_seeds = nullptr;
+    float4 *d_colors = nullptr;   // (r, g, b, 0) per pixel (PTGPU_COLOR_STRIDE_FLOATS)
+    uint32_t *d_pixels = nullptr;
+    uint2 *d_seeds = nullptr;
+    std::vector<float> color_staging; // host side of read_colors / write_colors (12 <-> 16 bytes per pixel)
     int *d_work = nullptr;      // work queue of the wavefront kernel: 2 + tiles words (device_params.h)
+    int *static_work = nullptr; // this device's copy of the file-scope `scratch` array (ptgpu_render_static)
     int work_queue = 2;         // PTGPU_OPT_WORK_QUEUE
-    bool queue_in_flight = false; // a work-queue launch was issued since the last check of its give-up word
+    // a work-queue launch was issued since the last check of its give-up word: [0] own queue, [1] static
+    bool queue_in_flight[2] = {false, false};
     int compute_units = 0;
 };
 
@@ -153,7 +158,8 @@ void free_image(ptgpu_ctx *c) {
     if (c->d_work) (void)hipFree(c->d_work);
     c->d_work = nullptr;
     c->d_colors = nullptr;
-    c->d_pixels = c->d_seeds = nullptr;
+    c->d_pixels = nullptr;
+    c->d_seeds = nullptr;
     c->width = c->height = 0;
 }
 
@@ -174,7 +180,21 @@ float as_float(int v) {
 #endif
 constexpr long long kQueueMaxUnits = PT_QUEUE_MAX_UNITS; // units of one work-queue launch (an int in the kernel)
 constexpr double kEnclosedMargin = 1e-5; // "inside a sphere" = closer to its centre than r (1 - margin)
-PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
+// The image a launch works on: the context's own buffers (ptgpu_resize) or, for ptgpu_render_static,
+// the caller's, with the work queue in the static array.
+struct ImageTarget {
+    int width, height;
+    float4 *colors;
+    uint32_t *pixels;
+    uint2 *seeds;
+    int *work;
+    bool is_static; // always the wavefront kernel with the work queue, whatever the options say
+};
+ImageTarget own_image(const ptgpu_ctx *c) {
+    return ImageTarget{c->width, c->height, c->d_colors, c->d_pixels, c->d_seeds, c->d_work, false};
+}
+
+PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes) {
     PtDeviceParams p{};
     p.prims = c->d_prims;
     p.shade = c->d_shade;
@@ -196,15 +216,15 @@ PtDeviceParams make_params(const ptgpu_ctx *c, int first_sample, int n_passes) {
     memcpy(p.sky1, s1, sizeof s1);
     memcpy(p.sky2, s2, sizeof s2);
     p.gamma = c->scene.gamma;
-    p.width = c->width;
-    p.height = c->height;
+    p.width = img.width;
+    p.height = img.height;
     p.current_sample = first_sample;
     p.n_passes = n_passes;
-    p.colors = c->d_colors;
-    p.pixels = c->d_pixels;
-    p.seeds = c->d_seeds;
-    p.tiles_x = (c->width + 7) / 8;
-    p.n_tiles = p.tiles_x * ((c->height + 7) / 8);
+    p.colors = img.colors;
+    p.pixels = img.pixels;
+    p.seeds = img.seeds;
+    p.tiles_x = (img.width + 7) / 8;
+    p.n_tiles = p.tiles_x * ((img.height + 7) / 8);
     p.tile_first = 0;
     p.tile_stride = 1;
     p.n_launch_tiles = p.n_tiles;
@@ -601,14 +621,14 @@ void pack_geometry(const pt_object *objects, uint32_t object_count, uint32_t lig
     }
 }
 
-int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
+int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes) {
     if (!c->have_scene) return fail(PTGPU_ERR_STATE, "render before ptgpu_set_scene");
     if (!c->have_camera) return fail(PTGPU_ERR_STATE, "render before ptgpu_set_camera");
-    if (!c->d_colors) return fail(PTGPU_ERR_STATE, "render before ptgpu_resize");
+    if (!img.colors) return fail(PTGPU_ERR_STATE, "render before ptgpu_resize");
     if (first_sample < 0 || n_passes < 0) return fail(PTGPU_ERR_ARGUMENT, "negative sample index or pass count");
     if (n_passes == 0) return PTGPU_OK;
     PtLaunchConfig cfg{};
-    PtDeviceParams probe = make_params(c, first_sample, 1);
+    PtDeviceParams probe = make_params(c, img, first_sample, 1);
     cfg.waves_per_group = c->waves_per_group;
     // One region per stream when the image has enough tiles to keep every region's launch wide.
     // Cheap scenes (a pass is tens of microseconds) gain nothing from overlapping tails and lose to
@@ -625,7 +645,8 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     // the tree in dense batches): large-object 614 -> 940, the bunny scene 161 -> 184 Mpaths/s; a
     // sphere hierarchy or a small mesh is not (complex 2 235 -> 2 081, table-and-mirror 1 772 -> 1 509).
     const bool big_mesh = probe.n_bnodes > 0 && probe.bvh_type == PT_TRIANGLE && probe.n_bslots >= 512;
-    const int kernel = c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
+    const int kernel = img.is_static                  ? PTGPU_KERNEL_WAVEFRONT
+                       : c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
                        : ((c->info.lights >= 2 || big_mesh) && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
                                                                                                  : PTGPU_KERNEL_MEGA);
     // a hierarchy too large for LDS is staged nodes only, where that pays: the wavefront kernel
@@ -675,8 +696,9 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     // cheaper per pass and run into the counter's rate: a mega kernel with the queue ran caustic at 25
     // instead of 49 Gpaths/s and cornell dl at 1.8 instead of 3.6.)
     const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
-                       (c->work_queue == 1 || (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT &&
-                                               probe.n_tiles >= 2048 && unit_passes * work >= 512));
+                       (img.is_static || c->work_queue == 1 ||
+                        (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT && probe.n_tiles >= 2048 &&
+                         unit_passes * work >= 512));
     if (queue) {
         // The kernel numbers its units with an int: a call of more than kQueueMaxUnits units (4K frame,
         // some 8 000 one-pass chunks) is issued as several launches, in order on the stream.
@@ -684,15 +706,15 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
         const long long passes_per_launch = chunks_per_launch * unit_passes;
         for (long long done = 0; done < n_passes; done += passes_per_launch) {
             const int n = (int)(n_passes - done < passes_per_launch ? n_passes - done : passes_per_launch);
-            PtDeviceParams p = make_params(c, first_sample + (int)done, n);
+            PtDeviceParams p = make_params(c, img, first_sample + (int)done, n);
             p.bvh_nodes_only = nodes_only && cfg.use_lds;
-            p.work = c->d_work;
+            p.work = img.work;
             p.unit_passes = (int)unit_passes;
-            // the counter and the per-tile words; the give-up word behind them is sticky until it is read
-            HIP_TRY(hipMemsetAsync(c->d_work, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
+            // the counter and the per-tile words; the give-up word in front of them is sticky until it is read
+            HIP_TRY(hipMemsetAsync(img.work + 1, 0, (1 + (size_t)p.n_tiles) * sizeof(int), c->stream));
             const int rc = launch(p, c->stream);
             if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
-            c->queue_in_flight = true;
+            c->queue_in_flight[img.is_static ? 1 : 0] = true;
         }
         return PTGPU_OK;
     }
@@ -704,7 +726,7 @@ int enqueue(ptgpu_ctx *c, int first_sample, int n_passes) {
     for (int done = 0; done < n_passes; done += chunk) {
         const int n = (n_passes - done < chunk) ? n_passes - done : chunk;
         for (int r = 0; r < regions; ++r) {
-            PtDeviceParams p = make_params(c, first_sample + done, n);
+            PtDeviceParams p = make_params(c, img, first_sample + done, n);
             p.bvh_nodes_only = nodes_only && cfg.use_lds;
             p.tile_first = r;
             p.tile_stride = regions;
@@ -1074,14 +1096,14 @@ int ptgpu_resize(ptgpu_ctx *ctx, int width, int height, const uint32_t *seeds) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     free_image(ctx);
     const size_t n = (size_t)width * height;
-    HIP_TRY(hipMalloc((void **)&ctx->d_colors, n * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&ctx->d_colors, n * sizeof(float4)));
     HIP_TRY(hipMalloc((void **)&ctx->d_pixels, n * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void **)&ctx->d_seeds, n * 2 * sizeof(uint32_t)));
     const size_t work_words = 2 + (size_t)((width + 7) / 8) * ((height + 7) / 8);
     HIP_TRY(hipMalloc((void **)&ctx->d_work, work_words * sizeof(int)));
     HIP_TRY(hipMemset(ctx->d_work, 0, work_words * sizeof(int)));
-    ctx->queue_in_flight = false;
-    HIP_TRY(hipMemset(ctx->d_colors, 0, n * 3 * sizeof(float)));
+    ctx->queue_in_flight[0] = false;
+    HIP_TRY(hipMemset(ctx->d_colors, 0, n * sizeof(float4)));
     HIP_TRY(hipMemset(ctx->d_pixels, 0, n * sizeof(uint32_t)));
     HIP_TRY(hipMemcpy(ctx->d_seeds, seeds, n * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->width = width;
@@ -1092,13 +1114,13 @@ int ptgpu_resize(ptgpu_ctx *ctx, int width, int height, const uint32_t *seeds) {
 int ptgpu_render_pass(ptgpu_ctx *ctx, int current_sample) {
     int rc = bind(ctx);
     if (rc) return rc;
-    return enqueue(ctx, current_sample, 1);
+    return enqueue(ctx, own_image(ctx), current_sample, 1);
 }
 
 int ptgpu_render(ptgpu_ctx *ctx, int first_sample, int n_passes) {
     int rc = bind(ctx);
     if (rc) return rc;
-    return enqueue(ctx, first_sample, n_passes);
+    return enqueue(ctx, own_image(ctx), first_sample, n_passes);
 }
 
 int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *elapsed_ms) {
@@ -1106,7 +1128,7 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
     if (rc) return rc;
     if (!elapsed_ms) return fail(PTGPU_ERR_ARGUMENT, "null elapsed_ms");
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = enqueue(ctx, first_sample, n_passes);
+    rc = enqueue(ctx, own_image(ctx), first_sample, n_passes);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->ev1));
@@ -1117,16 +1139,19 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
 // after the stream has drained: did a wave of a work-queue launch give up waiting for a tile's
 // previous pass (device_params.h)?  It cannot, unless a wave died; the image would be incomplete.
 static int check_work_queue(ptgpu_ctx *ctx) {
-    if (!ctx->queue_in_flight || !ctx->d_work) return PTGPU_OK;
-    ctx->queue_in_flight = false;
-    const size_t tiles = (size_t)((ctx->width + 7) / 8) * ((ctx->height + 7) / 8);
-    int gave_up = 0;
-    HIP_TRY(hipMemcpy(&gave_up, ctx->d_work + 1 + tiles, sizeof gave_up, hipMemcpyDeviceToHost));
-    if (gave_up) {
-        (void)hipMemset(ctx->d_work + 1 + tiles, 0, sizeof(int));
-        return fail(PTGPU_ERR_DEVICE, "work queue: a wave waited for a tile's previous pass beyond its limit; the frame is incomplete");
+    int *const queues[2] = {ctx->d_work, ctx->static_work};
+    int status = PTGPU_OK;
+    for (int q = 0; q < 2; ++q) {
+        if (!ctx->queue_in_flight[q] || !queues[q]) continue;
+        ctx->queue_in_flight[q] = false;
+        int gave_up = 0;
+        HIP_TRY(hipMemcpy(&gave_up, queues[q], sizeof gave_up, hipMemcpyDeviceToHost));
+        if (gave_up) {
+            (void)hipMemset(queues[q], 0, sizeof(int));
+            status = fail(PTGPU_ERR_DEVICE, "work queue: a wave waited for a tile's previous pass beyond its limit; the frame is incomplete");
+        }
     }
-    return PTGPU_OK;
+    return status;
 }
 
 int ptgpu_finish(ptgpu_ctx *ctx) {
@@ -1152,10 +1177,22 @@ int ptgpu_read_pixels(ptgpu_ctx *ctx, uint32_t *pixels) {
                      "ptgpu_read_pixels");
 }
 
+// The device keeps one float4 per pixel (device_params.h); the ABI's array is the reference's vec
+// layout, 3 floats per pixel (path-tracing.cl:87): the spare channel is dropped / added on the host.
 int ptgpu_read_colors(ptgpu_ctx *ctx, float *colors) {
     if (!ctx) return fail(PTGPU_ERR_ARGUMENT, "null context");
-    return read_back(ctx, colors, ctx->d_colors, (size_t)ctx->width * ctx->height * 3 * sizeof(float),
-                     "ptgpu_read_colors");
+    if (!colors) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_read_colors: null destination");
+    const size_t n = (size_t)ctx->width * ctx->height;
+    try {
+        ctx->color_staging.resize(n * PTGPU_COLOR_STRIDE_FLOATS);
+    } catch (const std::bad_alloc &) {
+        return fail(PTGPU_ERR_MEMORY, "out of host memory");
+    }
+    const int rc = read_back(ctx, ctx->color_staging.data(), ctx->d_colors, n * sizeof(float4), "ptgpu_read_colors");
+    if (rc) return rc;
+    const float *src = ctx->color_staging.data();
+    for (size_t i = 0; i < n; ++i) memcpy(colors + 3 * i, src + PTGPU_COLOR_STRIDE_FLOATS * i, 3 * sizeof(float));
+    return PTGPU_OK;
 }
 
 int ptgpu_read_seeds(ptgpu_ctx *ctx, uint32_t *seeds) {
@@ -1169,8 +1206,15 @@ int ptgpu_write_colors(ptgpu_ctx *ctx, const float *colors) {
     if (rc) return rc;
     if (!colors) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_write_colors: null source");
     if (!ctx->d_colors) return fail(PTGPU_ERR_STATE, "ptgpu_write_colors before ptgpu_resize");
-    HIP_TRY(hipMemcpyAsync(ctx->d_colors, colors, (size_t)ctx->width * ctx->height * 3 * sizeof(float),
-                           hipMemcpyHostToDevice, ctx->stream));
+    const size_t n = (size_t)ctx->width * ctx->height;
+    try {
+        ctx->color_staging.assign(n * PTGPU_COLOR_STRIDE_FLOATS, 0.f);
+    } catch (const std::bad_alloc &) {
+        return fail(PTGPU_ERR_MEMORY, "out of host memory");
+    }
+    float *dst = ctx->color_staging.data();
+    for (size_t i = 0; i < n; ++i) memcpy(dst + PTGPU_COLOR_STRIDE_FLOATS * i, colors + 3 * i, 3 * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(ctx->d_colors, dst, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PTGPU_OK;
 }
@@ -1192,7 +1236,7 @@ int ptgpu_scale_and_repack(ptgpu_ctx *ctx, float scale) {
     int rc = bind(ctx);
     if (rc) return rc;
     if (!ctx->d_colors || !ctx->have_scene) return fail(PTGPU_ERR_STATE, "no image or scene yet");
-    const PtDeviceParams p = make_params(ctx, 0, 0);
+    const PtDeviceParams p = make_params(ctx, own_image(ctx), 0, 0);
     rc = ptk_fast::launch_repack(p, scale, ctx->stream);
     if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     return PTGPU_OK;

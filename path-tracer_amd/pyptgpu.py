@@ -227,6 +227,7 @@ CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED, CULL_BALL = 0, 1, 2, 
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
+COLOR_STRIDE_FLOATS = 4  # PTGPU_COLOR_STRIDE_FLOATS: the device sample buffer is one float4 per pixel
 
 
 class SceneInfo(C.Structure):

@@ -42,7 +42,7 @@ def _worker(rank, world, port, out_dir, backend="gloo"):
     g.resize(W, H, pt.seed_block(W, H, rank))
     g.render(PASSES)
     g.finish()
-    t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), 3 * W * H), device="cuda:0")
+    t = torch.as_tensor(multigpu.DeviceArray(g.colors_device_ptr(), pt.COLOR_STRIDE_FLOATS * W * H), device="cuda:0")
     scale = multigpu.allreduce_mean_(t, world)
     torch.cuda.synchronize()
     g.scale_and_repack(scale)

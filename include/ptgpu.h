@@ -217,6 +217,48 @@ typedef struct ptgpu_scene_info {
 } ptgpu_scene_info;
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 
+/* What the last render call on this context launched (measurement aid, no reference counterpart):
+ * the library picks kernel, code instance, candidate sets and launch shape per scene, and bench.py
+ * names them in its output instead of re-deriving the rules. */
+enum { PTGPU_INSTANCE_PLAIN = 0, PTGPU_INSTANCE_BVH = 1, PTGPU_INSTANCE_HYBRID = 2, PTGPU_INSTANCE_BALL = 3 };
+typedef struct ptgpu_launch_info {
+    int kernel;            /* PTGPU_KERNEL_MEGA or _WAVEFRONT (AUTO resolved)                     */
+    int math;              /* PTGPU_MATH_*                                                        */
+    int instance;          /* PTGPU_INSTANCE_*: which build of the kernel source ran              */
+    int work_queue;        /* 1 = one launch for the call, units from the queue                   */
+    int unit_passes;       /* passes per queue unit (0 without the queue)                         */
+    int passes_per_launch; /* passes inside one launch                                            */
+    int regions;           /* concurrent region streams (1 with the queue)                        */
+    unsigned lds_bytes;    /* LDS of the staged records per workgroup (0 = read from global)      */
+    int bvh_nodes_only;    /* hierarchy staged nodes only                                         */
+    int shadow_cull;       /* PTGPU_CULL_* in effect (OFF when the scene has no tables)           */
+    int ray_bins;          /* shadow rays binned on triangle clusters                             */
+} ptgpu_launch_info;
+int ptgpu_get_launch_info(ptgpu_ctx *ctx, ptgpu_launch_info *info);
+
+/* Work the kernels EXECUTED since the last reset, summed over every kernel instance, per active
+ * lane (measurement aid, no reference counterpart; bench.py builds its roofline from it).  Only the
+ * counting build of the library (-DPT_COUNT_WORK=1: path-tracer_amd/variants/libptgpu_count.so,
+ * scripts/build_variants.sh) keeps them - it is slow and never the timed one; the regular library
+ * returns PTGPU_ERR_STATE.  Waits for the context's stream first. */
+enum {
+    PTGPU_WORK_SPHERE_TESTS = 0,   /* geomfunc.h:10-39, ~20 flops                                   */
+    PTGPU_WORK_TRIANGLE_TESTS_MT,  /* Moeller-Trumbore, geomfunc.h:45-78, ~52 flops                  */
+    PTGPU_WORK_TRIANGLE_TESTS_PLANES, /* plane form (fast build), ~32 flops                         */
+    PTGPU_WORK_BVH_NODES,          /* slab tests of the hierarchy walks, ~22 flops                   */
+    PTGPU_WORK_LIGHT_SAMPLES,      /* geomfunc.h:227-300 evaluated (after the plane-side test), ~70  */
+    PTGPU_WORK_LIGHT_POINTS,       /* sampled light point (part of a sample; once more for a binned ray) */
+    PTGPU_WORK_PLANE_SIDE_TESTS,   /* hit point against a light's plane, 5 flops                     */
+    PTGPU_WORK_SEGMENT_NEAR_TESTS, /* shadow segment against a cluster's bounding sphere, ~21        */
+    PTGPU_WORK_BALL_POINT_TESTS,   /* PTGPU_CULL_BALL end-point tests, ~8 each                       */
+    PTGPU_WORK_EXTENSION_RAYS,     /* closest-hit rays incl. their shading, ~120 beside the tests    */
+    PTGPU_WORK_SHADOW_RAYS,        /* any-hit rays traced                                            */
+    PTGPU_WORK_RNG_DRAWS,          /* GetRandom calls (integer work)                                 */
+    PTGPU_WORK_PATHS,
+    PTGPU_WORK_SLOTS = 16
+};
+int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters /* [PTGPU_WORK_SLOTS] */, int reset);
+
 /* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
  * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
  * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT, ENCLOSED or BALL (OFF:
@@ -225,7 +267,11 @@ int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
  * (sampling order), 0 when it is culled or is not a sphere/triangle, 2 (BALL) when sphere i is
  * tested by the ray's point at maxt instead of the ray.  *n_lights receives the number
  * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the
- * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves. */
+ * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves.
+ * No material table is passed: an object counts as a dielectric (it encloses nothing) when its
+ * material_id is 2, the slot of the reference's built-in glass (displayfunc.c:147-155);
+ * ptgpu_set_scene also looks at materials[material_id].type, so for a caller-made table that keeps
+ * glass in another slot the sets staged on the device can be larger than the ones returned here. */
 int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count,
                             int mode, uint8_t *keep, uint32_t *n_lights);
 

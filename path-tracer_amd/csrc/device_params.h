@@ -54,6 +54,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 constexpr int kLightQuads = 5;
 constexpr int kSphereGroup = 1, kTriGroup = 4; // primitives per shadow group, tested back to back with no exit check
@@ -122,34 +123,41 @@ struct PtLaunchConfig {
 };
 
 namespace ptk_fast {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
 namespace ptk_strict {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
 // the same kernels compiled with the BVH traversal in place of the linear scans (PT_BVH 1)
 namespace ptk_fast_bvh {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }
-namespace ptk_fast_hyb { // PT_BVH 2: extension rays through the hierarchy over the shadow order
+namespace ptk_fast_hyb {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only // PT_BVH 2: extension rays through the hierarchy over the shadow order
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }
 namespace ptk_strict_bvh {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }
 // PTGPU_CULL_BALL: the hybrid fast build and the strict build with the point test compiled in
 namespace ptk_fast_ball {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }
 namespace ptk_strict_ball {
+int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 }

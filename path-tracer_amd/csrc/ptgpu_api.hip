@@ -101,11 +101,11 @@ struct ptgpu_ctx {
     uint2 *d_seeds = nullptr;
     std::vector<float> color_staging; // host side of read_colors / write_colors (12 <-> 16 bytes per pixel)
     int *d_work = nullptr;      // work queue of the wavefront kernel: 2 + tiles words (device_params.h)
-    int *static_work = nullptr; // this device's copy of the file-scope `scratch` array (ptgpu_render_static)
     int work_queue = 2;         // PTGPU_OPT_WORK_QUEUE
     // a work-queue launch was issued since the last check of its give-up word: [0] own queue, [1] static
     bool queue_in_flight[2] = {false, false};
     int compute_units = 0;
+    ptgpu_launch_info last_launch{}; // what the last render call issued (ptgpu_get_launch_info)
 };
 
 namespace {
@@ -148,6 +148,8 @@ void free_scene(ptgpu_ctx *c) {
     c->d_smask_safe = c->d_smask_tight = c->d_smask_enclosed = c->d_smask_ball = nullptr;
     c->d_prims = c->d_shade = c->d_lights = nullptr;
     c->d_segs = nullptr;
+    c->enclosing.clear(); // what the ENCLOSED / BALL camera check walks: never the previous scene's
+    c->ball_groups = 0;
     c->have_scene = false;
 }
 
@@ -679,6 +681,25 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
         return strict ? ptk_strict::launch_wavefront(p, cfg, s) : ptk_fast::launch_wavefront(p, cfg, s);
     };
 
+    auto record = [&](const PtDeviceParams &p, bool queued, int unit, int per_launch, int n_regions) {
+        ptgpu_launch_info &li = c->last_launch;
+        li = ptgpu_launch_info{};
+        li.kernel = kernel;
+        li.math = c->math;
+        li.instance = p.n_bnodes ? PTGPU_INSTANCE_BVH : p.ball_groups ? PTGPU_INSTANCE_BALL : p.n_hnodes ? PTGPU_INSTANCE_HYBRID : PTGPU_INSTANCE_PLAIN;
+        li.work_queue = queued ? 1 : 0;
+        li.unit_passes = unit;
+        li.passes_per_launch = per_launch;
+        li.regions = n_regions;
+        li.lds_bytes = cfg.lds_bytes;
+        li.bvh_nodes_only = p.bvh_nodes_only;
+        li.shadow_cull = !p.smask                            ? PTGPU_CULL_OFF
+                         : p.smask == c->d_smask_safe        ? PTGPU_CULL_SAFE
+                         : p.smask == c->d_smask_tight       ? PTGPU_CULL_TIGHT
+                         : p.smask == c->d_smask_enclosed    ? PTGPU_CULL_ENCLOSED
+                                                             : PTGPU_CULL_BALL;
+        li.ray_bins = p.n_clusters > 0;
+    };
     cfg.compute_units = c->compute_units;
     // Work queue (PTGPU_OPT_WORK_QUEUE): one launch for the whole call.  Each unit costs a shared
     // counter increment and an agent-scope release / acquire (microseconds): AUTO takes it where a
@@ -715,6 +736,7 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
             const int rc = launch(p, c->stream);
             if (rc != 0) return fail(PTGPU_ERR_DEVICE, "kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
             c->queue_in_flight[img.is_static ? 1 : 0] = true;
+            record(p, true, (int)unit_passes, n, 1);
         }
         return PTGPU_OK;
     }
@@ -733,6 +755,7 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
             p.n_launch_tiles = (p.n_tiles - r + regions - 1) / regions;
             const int rc = launch(p, r == 0 ? c->stream : c->side[r - 1]);
             if (rc != 0 && launch_error == 0) launch_error = rc;
+            if (r == 0 && done == 0) record(p, false, 0, chunk, regions);
         }
         if (launch_error) break;
     }
@@ -936,10 +959,10 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     if (info.lights >= (1u << 18)) st.cluster_bounds.clear(); // the near-queue tag holds 18 bits of light index
     for (size_t l = 0; l < st.light_clusters.size(); ++l)   // l1.w is free in both light kinds
         dlights[kLightQuads * l + 1].w = as_float(st.cluster_bounds.empty() ? 0 : (int)st.light_clusters[l]);
-    ctx->ball_groups = 0;
+    unsigned ball_groups = 0;
     for (size_t l = 0; l < st.light_ball.size(); ++l) { // l2.w is free in both light kinds
         dlights[kLightQuads * l + 2].w = as_float((int)st.light_ball[l]);
-        ctx->ball_groups |= st.light_ball[l];
+        ball_groups |= st.light_ball[l];
     }
     std::vector<float4> sshade;
     for (int slot : st.prim_of_slot)
@@ -1006,6 +1029,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     HIP_TRY(upload(ctx->d_sprims_planes, st.sprims_planes));
     HIP_TRY(upload(ctx->d_sshade, sshade));
     if (use_tables) {
+        ctx->ball_groups = ball_groups;
         HIP_TRY(upload(ctx->d_smask_safe, st.safe));
         HIP_TRY(upload(ctx->d_smask_tight, st.tight));
         HIP_TRY(upload(ctx->d_smask_enclosed, st.enclosed));
@@ -1070,6 +1094,36 @@ int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uin
         for (size_t i = 0; i < n_prims; ++i)
             keep[l * object_count + geo.object_of_prim[i]] = by_prim[l * n_prims + i];
     return PTGPU_OK;
+}
+
+int ptgpu_get_launch_info(ptgpu_ctx *ctx, ptgpu_launch_info *info) {
+    if (!ctx || !info) return fail(PTGPU_ERR_ARGUMENT, "null argument");
+    *info = ctx->last_launch;
+    return PTGPU_OK;
+}
+
+int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters, int reset) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!counters) return fail(PTGPU_ERR_ARGUMENT, "null argument");
+#if PT_COUNT_WORK
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < PTGPU_WORK_SLOTS; ++i) counters[i] = 0;
+    int bad = 0;
+    bad |= ptk_fast::work_counters(counters, reset);
+    bad |= ptk_strict::work_counters(counters, reset);
+    bad |= ptk_fast_bvh::work_counters(counters, reset);
+    bad |= ptk_strict_bvh::work_counters(counters, reset);
+    bad |= ptk_fast_hyb::work_counters(counters, reset);
+    bad |= ptk_fast_ball::work_counters(counters, reset);
+    bad |= ptk_strict_ball::work_counters(counters, reset);
+    if (bad) return fail(PTGPU_ERR_DEVICE, "reading the work counters failed");
+    return PTGPU_OK;
+#else
+    (void)reset;
+    return fail(PTGPU_ERR_STATE, "this libptgpu.so is not the counting build (scripts/build_variants.sh builds "
+                                 "path-tracer_amd/variants/libptgpu_count.so with -DPT_COUNT_WORK=1)");
+#endif
 }
 
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info) {
@@ -1139,7 +1193,7 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
 // after the stream has drained: did a wave of a work-queue launch give up waiting for a tile's
 // previous pass (device_params.h)?  It cannot, unless a wave died; the image would be incomplete.
 static int check_work_queue(ptgpu_ctx *ctx) {
-    int *const queues[2] = {ctx->d_work, ctx->static_work};
+    int *const queues[2] = {ctx->d_work, nullptr};
     int status = PTGPU_OK;
     for (int q = 0; q < 2; ++q) {
         if (!ctx->queue_in_flight[q] || !queues[q]) continue;

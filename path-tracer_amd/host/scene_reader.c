@@ -31,6 +31,8 @@
 
 #define PI_F 3.14159265358979323846f
 #define N_BUILTIN_MATERIALS 3
+#define PTHOST_MAX_USER_MATERIALS (1u << 20)
+#define PTHOST_MAX_OBJECTS (1u << 24)
 
 static __thread char g_error[512];
 
@@ -198,6 +200,12 @@ int pthost_load_scene(const char *path, const char *model_dir, int width, int he
         pthost_set_error("Failed to read the number of materials: %d", c);
         goto fail;
     }
+    /* upstream adds without a bound (displayfunc.c:147): the sum wraps for counts near 2^32, the
+     * table comes out shorter than the three built-ins and they are written past its end */
+    if (user_materials > PTHOST_MAX_USER_MATERIALS) {
+        pthost_set_error("Too many materials: %u (at most %u)", user_materials, PTHOST_MAX_USER_MATERIALS);
+        goto fail;
+    }
     out->scene.material_count = user_materials + N_BUILTIN_MATERIALS;
     out->materials = (pt_material *)calloc(out->scene.material_count, sizeof(pt_material));
     if (!out->materials) {
@@ -251,6 +259,10 @@ int pthost_load_scene(const char *path, const char *model_dir, int width, int he
     c = fscanf(f, "objects %u ", &declared);
     if (c < 1) {
         pthost_set_error("Failed to read object count: %d", c);
+        goto fail;
+    }
+    if (declared > PTHOST_MAX_OBJECTS) { /* what ptgpu_set_scene takes (2^24) */
+        pthost_set_error("Too many objects: %u (at most %u)", declared, PTHOST_MAX_OBJECTS);
         goto fail;
     }
     out->objects = (pt_object *)calloc(declared ? declared : 1, sizeof(pt_object));

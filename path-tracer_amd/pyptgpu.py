@@ -242,45 +242,79 @@ GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_s
                "ptgpu_resize", "ptgpu_render_pass", "ptgpu_render", "ptgpu_render_timed", "ptgpu_finish",
                "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
                "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
-               "ptgpu_shadow_candidates", "ptgpu_last_error"]
+               "ptgpu_shadow_candidates", "ptgpu_last_error",
+               "ptgpu_get_launch_info", "ptgpu_work_counters"]
+
+
+class LaunchInfo(C.Structure):
+    _fields_ = [("kernel", C.c_int), ("math", C.c_int), ("instance", C.c_int), ("work_queue", C.c_int),
+                ("unit_passes", C.c_int), ("passes_per_launch", C.c_int), ("regions", C.c_int),
+                ("lds_bytes", C.c_uint), ("bvh_nodes_only", C.c_int), ("shadow_cull", C.c_int), ("ray_bins", C.c_int)]
+
+
+INSTANCE_NAMES = {0: "plain", 1: "bvh", 2: "hybrid", 3: "ball"}
+WORK_SLOTS = ("sphere_tests", "triangle_tests_mt", "triangle_tests_planes", "bvh_nodes", "light_samples",
+              "light_points", "plane_side_tests", "segment_near_tests", "ball_point_tests", "extension_rays",
+              "shadow_rays", "rng_draws", "paths")
 
 
 class GpuError(RuntimeError):
     pass
 
 
-def gpu():
-    """libptgpu.so, loaded once.  Raises if the HIP extension has not been built."""
+VARIANT_DIR = os.path.join(HERE, "variants")
+_variants = {}
+
+
+def variant_path(name):
+    """A measurement / test build of the library (scripts/build_variants.sh): count, giveup."""
+    return os.path.join(VARIANT_DIR, "libptgpu_%s.so" % name)
+
+
+def gpu(path=None):
+    """libptgpu.so (or, with `path`, a variant build of it), loaded once per path.  Raises if the HIP
+    extension has not been built."""
     global _gpu
+    if path is not None:
+        if path not in _variants:
+            if not os.path.exists(path):
+                raise GpuError("%s is missing: build it with scripts/build_variants.sh" % path)
+            _variants[path] = _bind(C.CDLL(path))
+        return _variants[path]
     if _gpu is None:
         path = os.environ.get("PTGPU_LIB") or os.path.join(HERE, "libptgpu.so")  # PTGPU_LIB: A/B builds
         if not os.path.exists(path):
             raise GpuError("libptgpu.so is missing: build it with `make -C path-tracer_amd/csrc` "
                            "(there is no CPU fallback for the radiance path)")
-        lib = C.CDLL(path)
-        lib.ptgpu_last_error.restype = C.c_char_p
-        vp = C.c_void_p
-        lib.ptgpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
-        lib.ptgpu_destroy.argtypes = [vp]
-        lib.ptgpu_set_option.argtypes = [vp, C.c_int, C.c_int]
-        lib.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(Scene)]
-        lib.ptgpu_set_camera.argtypes = [vp, C.POINTER(Camera)]
-        lib.ptgpu_resize.argtypes = [vp, C.c_int, C.c_int, vp]
-        lib.ptgpu_render_pass.argtypes = [vp, C.c_int]
-        lib.ptgpu_render.argtypes = [vp, C.c_int, C.c_int]
-        lib.ptgpu_render_timed.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
-        lib.ptgpu_finish.argtypes = [vp]
-        lib.ptgpu_read_pixels.argtypes = [vp, vp]
-        lib.ptgpu_read_colors.argtypes = [vp, vp]
-        lib.ptgpu_read_seeds.argtypes = [vp, vp]
-        lib.ptgpu_write_colors.argtypes = [vp, vp]
-        lib.ptgpu_colors_device_ptr.argtypes = [vp, C.POINTER(vp)]
-        lib.ptgpu_stream.argtypes = [vp, C.POINTER(vp)]
-        lib.ptgpu_scale_and_repack.argtypes = [vp, C.c_float]
-        lib.ptgpu_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
-        lib.ptgpu_shadow_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.POINTER(C.c_uint32)]
-        _gpu = lib
+        _gpu = _bind(C.CDLL(path))
     return _gpu
+
+
+def _bind(lib):
+    lib.ptgpu_last_error.restype = C.c_char_p
+    vp = C.c_void_p
+    lib.ptgpu_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+    lib.ptgpu_destroy.argtypes = [vp]
+    lib.ptgpu_set_option.argtypes = [vp, C.c_int, C.c_int]
+    lib.ptgpu_set_scene.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, C.POINTER(Scene)]
+    lib.ptgpu_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    lib.ptgpu_resize.argtypes = [vp, C.c_int, C.c_int, vp]
+    lib.ptgpu_render_pass.argtypes = [vp, C.c_int]
+    lib.ptgpu_render.argtypes = [vp, C.c_int, C.c_int]
+    lib.ptgpu_render_timed.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    lib.ptgpu_finish.argtypes = [vp]
+    lib.ptgpu_read_pixels.argtypes = [vp, vp]
+    lib.ptgpu_read_colors.argtypes = [vp, vp]
+    lib.ptgpu_read_seeds.argtypes = [vp, vp]
+    lib.ptgpu_write_colors.argtypes = [vp, vp]
+    lib.ptgpu_colors_device_ptr.argtypes = [vp, C.POINTER(vp)]
+    lib.ptgpu_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.ptgpu_scale_and_repack.argtypes = [vp, C.c_float]
+    lib.ptgpu_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.ptgpu_shadow_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.POINTER(C.c_uint32)]
+    lib.ptgpu_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
+    lib.ptgpu_work_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
+    return lib
 
 
 def shadow_candidates(sc, mode, light_count=None):
@@ -301,8 +335,8 @@ class Gpu:
 
     def __init__(self, device=0, integrator=INTEGRATOR_PT, kernel=None, math=None, lds=None, streams=None,
                  passes_per_launch=None, waves_per_group=None, shadow_cull=None, ray_bins=None, bvh=None,
-                 work_queue=None):
-        self.lib = gpu()
+                 work_queue=None, lib=None):
+        self.lib = gpu(lib)
         self.ctx = C.c_void_p()
         self._ok(self.lib.ptgpu_create(C.byref(self.ctx), device, integrator))
         if kernel is not None:
@@ -400,6 +434,17 @@ class Gpu:
         info = SceneInfo()
         self._ok(self.lib.ptgpu_get_scene_info(self.ctx, C.byref(info)))
         return {n: (float if t is C.c_float else int)(getattr(info, n)) for n, t in info._fields_}
+
+    def launch_info(self):
+        info = LaunchInfo()
+        self._ok(self.lib.ptgpu_get_launch_info(self.ctx, C.byref(info)))
+        return {n: int(getattr(info, n)) for n, _ in info._fields_}
+
+    def work_counters(self, reset=True):
+        """Counting build only (lib=variant_path("count")): executed work since the last reset."""
+        out = (C.c_ulonglong * 16)()
+        self._ok(self.lib.ptgpu_work_counters(self.ctx, out, 1 if reset else 0))
+        return {n: int(out[i]) for i, n in enumerate(WORK_SLOTS)}
 
     def close(self):
         if self.ctx:

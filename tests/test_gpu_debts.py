@@ -1,0 +1,112 @@
+"""Small correctness debts of the device plumbing (VERDICT r01 "Smaller"): the work queue's give-up
+path, an explicit waves-per-group that does not fit a CU's LDS, the launch report.  Every call goes
+through the C-ABI; the give-up case runs a TEST BUILD of the same library (libptgpu_giveup.so,
+scripts/build_variants.sh: the wait for a tile's previous chunk gives up at the first failed poll)."""
+import numpy as np
+import pytest
+
+import pyptgpu as pt
+from conftest import same_bits
+from test_gpu_synthetic import icosphere, make_scene, room, sphere, triangles
+
+pytestmark = pytest.mark.gpu
+
+
+def test_work_queue_give_up_is_reported_once_and_the_context_stays_usable():
+    w, h = 64, 64                                    # 64 tiles: the chip takes every chunk of every tile at once
+    sc = pt.LoadedScene("cornell-large", w, h)
+    seeds = pt.seed_block(w, h)
+    g = pt.Gpu(0, 0, kernel=pt.KERNEL_WAVEFRONT, math=pt.MATH_STRICT, work_queue=1, lib=pt.variant_path("giveup"))
+    g.set_scene(sc)
+    g.resize(w, h, seeds)
+    g.render(64)                                     # 4 chunks of 16 passes: chunk 1 waits for chunk 0, and gives up
+    assert g.launch_info()["work_queue"] == 1 and g.launch_info()["unit_passes"] == 16
+    with pytest.raises(pt.GpuError, match="work queue.*incomplete"):
+        g.finish()
+    g.finish()                                       # reported once: the word was read and cleared
+    # the same context renders again (a launch per pass: nothing to wait for), and the image is the
+    # regular library's
+    g.set_option(pt.OPT_WORK_QUEUE, 0)
+    g.resize(w, h, seeds)
+    g.render(3)
+    g.finish()
+    ref = pt.Gpu(0, 0, kernel=pt.KERNEL_WAVEFRONT, math=pt.MATH_STRICT, work_queue=1)
+    ref.set_scene(sc)
+    ref.resize(w, h, seeds)
+    ref.render(3)
+    assert same_bits(g.colors(), ref.colors()) and (g.pixels() == ref.pixels()).all() and (g.seeds() == ref.seeds()).all()
+    g.close()
+    ref.close()
+
+
+def test_sixteen_waves_per_group_next_to_92_kb_of_records_comes_down_to_what_fits():
+    # 1 920 triangles + 7 spheres: 92.5 KB of staged records (limit 96 KB); 16 waves of scratch would
+    # make 162 KB, beyond the CU's 160 KB - the launcher takes 12 instead of failing the launch
+    objs = room() + [sphere(6, (0, 70, 80), emission=(12, 12, 12))]
+    objs.append(triangles(icosphere((10, 20, 80), 14, 3)))
+    objs.append(triangles(icosphere((-25, 15, 60), 9, 2), color=(.3, .8, .4)))
+    for k in range(4):
+        objs.append(triangles(icosphere((-30 + 18 * k, 45, 100), 5, 1)))
+    w, h = 64, 48
+    sc = make_scene(objs, w, h)
+    out = {}
+    for waves in (8, 16):
+        g = pt.Gpu(0, 0, kernel=pt.KERNEL_WAVEFRONT, math=pt.MATH_STRICT, bvh=pt.BVH_OFF, shadow_cull=pt.CULL_OFF,
+                   waves_per_group=waves)
+        g.set_scene(sc)
+        assert g.scene_info()["triangles"] == 1920
+        g.resize(w, h, pt.seed_block(w, h))
+        g.render(2)
+        g.finish()
+        assert 90 * 1024 < g.launch_info()["lds_bytes"] <= 96 * 1024
+        out[waves] = (g.colors(), g.pixels(), g.seeds())
+        g.close()
+    assert same_bits(out[8][0], out[16][0]) and (out[8][1] == out[16][1]).all() and (out[8][2] == out[16][2]).all()
+
+
+def test_launch_info_names_what_ran():
+    w, h = 1024, 768
+    g = pt.Gpu(0, 0)
+    g.set_scene(pt.LoadedScene("cornell", w, h))
+    g.resize(w, h, pt.seed_block(w, h))
+    g.render(2)
+    g.finish()
+    li = g.launch_info()
+    assert (li["kernel"], li["math"], li["instance"]) == (pt.KERNEL_WAVEFRONT, pt.MATH_FAST, 2)   # the fast hybrid
+    assert li["work_queue"] == 1 and li["unit_passes"] == 1 and li["shadow_cull"] == pt.CULL_ENCLOSED and li["ray_bins"] == 1
+    g.set_scene(pt.LoadedScene("caustic", w, h))
+    g.resize(w, h, pt.seed_block(w, h))
+    g.render(2)
+    g.finish()
+    li = g.launch_info()
+    assert (li["kernel"], li["instance"], li["work_queue"], li["shadow_cull"]) == (pt.KERNEL_MEGA, 0, 0, pt.CULL_OFF)
+    g.close()
+
+
+def test_counting_build_counts_and_renders_the_same_image():
+    w, h = 64, 48
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    out = {}
+    for lib in (None, pt.variant_path("count")):
+        g = pt.Gpu(0, 0, kernel=pt.KERNEL_WAVEFRONT, lib=lib)
+        g.set_scene(sc)
+        g.resize(w, h, seeds)
+        if lib:
+            g.work_counters(reset=True)
+        g.render(2)
+        g.finish()
+        out[lib] = (g.colors(), g.seeds())
+        if lib:
+            work = g.work_counters()
+            assert work["paths"] == 2 * w * h
+            assert 4 * work["paths"] < work["extension_rays"] <= 7 * work["paths"]
+            # every light sample was preceded by a plane-side test that did not reject it
+            assert 0 < work["light_samples"] < work["plane_side_tests"]
+            assert work["triangle_tests_planes"] > 0 and work["triangle_tests_mt"] == 0 and work["bvh_nodes"] > 0
+        else:
+            with pytest.raises(pt.GpuError, match="counting build"):
+                g.work_counters()
+        g.close()
+    assert same_bits(out[None][0], out[pt.variant_path("count")][0])
+    assert (out[None][1] == out[pt.variant_path("count")][1]).all()

@@ -83,6 +83,8 @@ def test_missing_header_defaults(tmp_path):
     ("camera 0 0 0 0 0 0\nmaterials 0\nobjects 1\nsphere 1 0 0 0\n", "sphere"),
     ("camera 0 0 0 0 0 0\nmaterials 0\nobjects 1\nsphere 1 0 0 0 0 0 0 1 1 1 9\n", "material type"),
     ("camera 0 0 0 0 0 0\nmaterials 1\nmatte 1 1\nobjects 0\n", "matte"),
+    ("camera 0 0 0 0 0 0\nmaterials 4294967293\nobjects 0\n", "Too many materials"),   # + 3 built-ins wraps to 0
+    ("camera 0 0 0 0 0 0\nmaterials 0\nobjects 16777217\n", "Too many objects"),
     ("camera 0 0 0 0 0 0\nmaterials 0\nobjects 1\nmodel nosuch.obj 0 0 0 1 1 1 0 0 0 1 1 1 0\n", "cannot open"),
 ])
 def test_parse_errors(tmp_path, text, msg):

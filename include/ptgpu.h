@@ -169,6 +169,26 @@ int ptgpu_render(ptgpu_ctx *ctx, int first_sample, int n_passes);
  * returns the elapsed device time in milliseconds.  (Measurement aid, no reference counterpart.) */
 int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *elapsed_ms);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory - code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc: ptgpu_render into image
+ * buffers the CALLER owns, with the wavefront kernel's work queue (counter + one word per 8x8 tile,
+ * what ptgpu_resize otherwise allocates next to the image) in a static device array of the library.
+ * The call allocates and frees nothing, on the device or through any library.
+ *   colors_dev  W*H float4 (r, g, b, 0) at [(H-1-y)*W+x]: running mean, read unless first_sample == 0
+ *   pixels_dev  W*H uint32 at [y*W+x], written
+ *   seeds_dev   2*W*H uint32, pixel (x, y) at [2*(y*W+x)], read and written
+ * (device pointers, 16 / 4 / 8-byte aligned).  Needs ptgpu_set_scene and ptgpu_set_camera, not
+ * ptgpu_resize.  Always the wavefront kernel with the work queue, whatever PTGPU_OPT_KERNEL /
+ * PTGPU_OPT_WORK_QUEUE say: the same image, bit for bit, as ptgpu_render with those two options set
+ * to WAVEFRONT and 1.  Asynchronous on the context's stream; ptgpu_finish as usual.
+ * Limit: PTGPU_STATIC_MAX_TILES tiles (a 4096x4096 frame; 1 MiB of device memory per GPU, held until
+ * the process ends); a larger frame is refused with PTGPU_ERR_ARGUMENT.  Every call on one GPU shares
+ * that GPU's array: calls that overlap on a GPU (two contexts, or two streams' worth of work from
+ * different threads) race - serialise them, e.g. ptgpu_finish between contexts. */
+#define PTGPU_STATIC_MAX_TILES 262142
+int ptgpu_render_static(ptgpu_ctx *ctx, int width, int height, int first_sample, int n_passes,
+                        void *colors_dev, uint32_t *pixels_dev, uint32_t *seeds_dev);
+
 /* replaces clFinish(), reference main-gpu.c:786 */
 int ptgpu_finish(ptgpu_ctx *ctx);
 

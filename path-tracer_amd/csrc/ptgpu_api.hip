@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -18,6 +19,31 @@
 #include "bvh_build.h"
 #include "device_params.h"
 #include "ptgpu.h"
+
+// ptgpu_render_static: the work queue of the wavefront kernel for callers that cannot allocate.
+// One copy per GPU, held until the process ends; every call on a GPU shares that GPU's copy.
+// In host code the name below is only a stand-in for the symbol: its device address is looked up once
+// per device (static_queue_of) and only that address is ever handed to memsets, copies and kernels.
+static constexpr size_t kStaticQueueWords = (size_t)PTGPU_STATIC_MAX_TILES + 2; // give-up word, counter, one word per tile
+static __device__ __align__(256) int scratch[kStaticQueueWords];
+
+static constexpr int kMaxDevices = 64;
+static std::mutex g_static_mutex;
+static int *g_static_queue[kMaxDevices] = {}; // per device: address of ITS copy of `scratch`
+
+// `device` must be the current device.  Allocates nothing: the array is part of the loaded code object.
+static int static_queue_of(int device, int **out) {
+    if (device < 0 || device >= kMaxDevices) return -1;
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (!g_static_queue[device]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return (int)(e != hipSuccess ? e : hipErrorInvalidSymbol);
+        g_static_queue[device] = (int *)ptr;
+    }
+    *out = g_static_queue[device];
+    return 0;
+}
 
 namespace {
 
@@ -101,6 +127,7 @@ struct ptgpu_ctx {
     uint2 *d_seeds = nullptr;
     std::vector<float> color_staging; // host side of read_colors / write_colors (12 <-> 16 bytes per pixel)
     int *d_work = nullptr;      // work queue of the wavefront kernel: 2 + tiles words (device_params.h)
+    int *static_work = nullptr; // this device's copy of the file-scope `scratch` array (ptgpu_render_static)
     int work_queue = 2;         // PTGPU_OPT_WORK_QUEUE
     // a work-queue launch was issued since the last check of its give-up word: [0] own queue, [1] static
     bool queue_in_flight[2] = {false, false};
@@ -799,6 +826,14 @@ int ptgpu_create(ptgpu_ctx **out, int device_ordinal, int integrator) {
     c->device = device_ordinal;
     c->integrator = integrator;
     c->compute_units = prop.multiProcessorCount;
+    {   // this device's copy of the static work queue (ptgpu_render_static), with the device current
+        const int e = static_queue_of(device_ordinal, &c->static_work);
+        if (e != 0) {
+            delete c;
+            return fail(PTGPU_ERR_DEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", device_ordinal,
+                        e > 0 ? hipGetErrorString((hipError_t)e) : "device ordinal beyond the table");
+        }
+    }
     auto make_queues = [&]() -> int {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&c->ev0));
@@ -1177,6 +1212,24 @@ int ptgpu_render(ptgpu_ctx *ctx, int first_sample, int n_passes) {
     return enqueue(ctx, own_image(ctx), first_sample, n_passes);
 }
 
+int ptgpu_render_static(ptgpu_ctx *ctx, int width, int height, int first_sample, int n_passes,
+                        void *colors_dev, uint32_t *pixels_dev, uint32_t *seeds_dev) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (!colors_dev || !pixels_dev || !seeds_dev) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_render_static: null buffer");
+    if (width <= 0 || height <= 0) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_render_static: image size %dx%d out of range", width, height);
+    const long long tiles = (long long)((width + 7) / 8) * ((height + 7) / 8);
+    if (tiles > PTGPU_STATIC_MAX_TILES)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_render_static: %dx%d is %lld tiles of 8x8 pixels, beyond the %d the static work "
+                                        "queue holds (use ptgpu_resize + ptgpu_render for such a frame)",
+                    width, height, tiles, PTGPU_STATIC_MAX_TILES);
+    if (((uintptr_t)colors_dev & 15u) || ((uintptr_t)seeds_dev & 7u) || ((uintptr_t)pixels_dev & 3u))
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_render_static: colours must be 16-byte, seeds 8-byte, pixels 4-byte aligned");
+    if (!ctx->static_work) return fail(PTGPU_ERR_STATE, "ptgpu_render_static: no static work queue on this device");
+    const ImageTarget img{width, height, (float4 *)colors_dev, pixels_dev, (uint2 *)seeds_dev, ctx->static_work, true};
+    return enqueue(ctx, img, first_sample, n_passes);
+}
+
 int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *elapsed_ms) {
     int rc = bind(ctx);
     if (rc) return rc;
@@ -1193,7 +1246,7 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
 // after the stream has drained: did a wave of a work-queue launch give up waiting for a tile's
 // previous pass (device_params.h)?  It cannot, unless a wave died; the image would be incomplete.
 static int check_work_queue(ptgpu_ctx *ctx) {
-    int *const queues[2] = {ctx->d_work, nullptr};
+    int *const queues[2] = {ctx->d_work, ctx->static_work};
     int status = PTGPU_OK;
     for (int q = 0; q < 2; ++q) {
         if (!ctx->queue_in_flight[q] || !queues[q]) continue;

@@ -242,7 +242,7 @@ GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_s
                "ptgpu_resize", "ptgpu_render_pass", "ptgpu_render", "ptgpu_render_timed", "ptgpu_finish",
                "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
                "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
-               "ptgpu_shadow_candidates", "ptgpu_last_error",
+               "ptgpu_shadow_candidates", "ptgpu_last_error", "ptgpu_render_static",
                "ptgpu_get_launch_info", "ptgpu_work_counters"]
 
 
@@ -303,6 +303,7 @@ def _bind(lib):
     lib.ptgpu_render.argtypes = [vp, C.c_int, C.c_int]
     lib.ptgpu_render_timed.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_float)]
     lib.ptgpu_finish.argtypes = [vp]
+    lib.ptgpu_render_static.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.ptgpu_read_pixels.argtypes = [vp, vp]
     lib.ptgpu_read_colors.argtypes = [vp, vp]
     lib.ptgpu_read_seeds.argtypes = [vp, vp]
@@ -315,6 +316,71 @@ def _bind(lib):
     lib.ptgpu_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
     lib.ptgpu_work_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     return lib
+
+
+_hip = None
+
+
+def hip_runtime():
+    """The HIP runtime libptgpu.so itself is linked to (found among this process's mappings), for
+    callers that own device buffers (ptgpu_render_static).  A second copy of the runtime in one
+    process - torch ships its own - does not find the GPU once this one has it."""
+    global _hip
+    if _hip is None:
+        gpu()
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise GpuError("libamdhip64 is not mapped: libptgpu.so did not load its HIP runtime")
+        lib = C.CDLL(path)
+        lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        lib.hipFree.argtypes = [C.c_void_p]
+        lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        lib.hipGetErrorString.restype = C.c_char_p
+        lib.hipGetErrorString.argtypes = [C.c_int]
+        _hip = lib
+    return _hip
+
+
+class DeviceBuffer:
+    """Device memory the CALLER owns (hipMalloc through hip_runtime())."""
+
+    def __init__(self, nbytes):
+        self.lib = hip_runtime()
+        self.nbytes = nbytes
+        self.ptr = C.c_void_p()
+        self._ok(self.lib.hipMalloc(C.byref(self.ptr), max(nbytes, 1)))
+        self._ok(self.lib.hipMemset(self.ptr, 0, max(nbytes, 1)))
+
+    def _ok(self, e):
+        if e != 0:
+            raise GpuError("HIP error %d: %s" % (e, self.lib.hipGetErrorString(e).decode()))
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes == self.nbytes
+        self._ok(self.lib.hipMemcpy(self.ptr, _ptr(a), a.nbytes, 1))   # hipMemcpyHostToDevice
+
+    def download(self, dtype):
+        out = np.empty(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._ok(self.lib.hipMemcpy(_ptr(out), self.ptr, self.nbytes, 2))   # hipMemcpyDeviceToHost (blocking)
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.lib.hipFree(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def shadow_candidates(sc, mode, light_count=None):
@@ -401,6 +467,10 @@ class Gpu:
 
     def finish(self):
         self._ok(self.lib.ptgpu_finish(self.ctx))
+
+    def render_static(self, w, h, first_sample, n_passes, colors_dev, pixels_dev, seeds_dev):
+        """ptgpu_render_static: raw device addresses of caller-owned buffers; allocates nothing."""
+        self._ok(self.lib.ptgpu_render_static(self.ctx, w, h, first_sample, n_passes, colors_dev, pixels_dev, seeds_dev))
 
     def pixels(self):
         out = np.empty(self.w * self.h, dtype=np.uint32)

@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py - Mpaths/s of the radiance path on scenes/cornell.txt 1024x768 (BASELINE.json config 2).
+"""bench.py - Mpaths/s of the radiance path; default workload scenes/cornell.txt 1024x768, path tracing
+(BASELINE.json config 2).  Other configs: --scene materials|caustic|obj-model|obj-model-bunny|cornell-large,
+--integrator pt|dl, --width/--height.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step = `--passes` progressive passes (one path per pixel per pass) over the whole frame, issued
-through the C-ABI as ONE render call (the library splits it into launches: per pass and image region
-for this workload).  Inputs (scene records, seeds, colour buffer) are resident
-in HBM before the timed region; the region is K steps bracketed by a barrier + device sync, MAX over
-ranks.  With N > 1 each rank renders from its own seed block and the colour buffers are summed with
-one RCCL all-reduce inside the timed region (weak scaling: per-GPU work is fixed).
+A step = `--passes` progressive passes (one path per pixel per pass) over the whole frame, issued through the
+C-ABI as ONE render call (for the default workload the library makes it one launch of the work-queue kernel).
+The defaults time 16 x 64 = 1 024 spp, the sample count BASELINE.json's config names.  Inputs (scene records,
+seeds, sample buffer) are resident in HBM before the timed region; the region is K steps bracketed by a barrier
++ device sync, MAX over ranks.  With N > 1 each rank renders from its own seed block and the sample buffers are
+summed with one RCCL all-reduce inside the timed region (weak scaling: per-GPU work is fixed).  Started WITHOUT
+a launcher and with --gpus N > 1, it starts its own N ranks (torch.distributed.run) before touching the GPU.
 
 The JSON line also carries
-  roofline     FP32 VALU: algorithmic flops F per path x paths per launch / average
-               launch duration from HIP events on the library's stream, against 157.3 TFLOP/s.  F is
-               counted by the CPU oracle on a sample of the same scene while it replays the product's
-               shadow-ray candidate sets (the tests the algorithm the kernel runs has to make);
-               the reference's brute-force count is reported beside it as reference_equivalent_*
-               and is NOT what `achieved` is built from.
-  cpu_baseline the CPU oracle (a bit-exact port of the reference's main-cpu.c path) timed on this
-               host's cores on a bounded sample of the same scene.
+  roofline     bound FP32 VALU.  `achieved` = flops the kernel EXECUTES per path x paths per
+               step / the step's HIP-event time.  The executed work is counted by the kernel itself: the
+               counting build of the library (-DPT_COUNT_WORK=1, same source, one atomic per wave and event)
+               renders a reduced frame of the same scene with the same options outside the timed region and
+               reports primitive tests, hierarchy node tests, light samples ... per ACTIVE lane; each is
+               weighted with its flop count (FLOPS below, FMA = 2).  `valu_fp32_issued` is the second,
+               independent figure: FP32 VALU instructions the hardware issued (committed rocprofv3 PMC run of
+               the same workload, profiles/r02) x 64 lanes x the measured active-lane share / this run's step
+               time.  The reference's brute-force count is reported beside them as reference_equivalent_* and
+               is NOT what `frac` is built from.
+  image_error  the benchmarked (fast) build against the strict build - which equals the reference bit for bit
+               (tests) - same seeds, same spp, full frame: RMSE, mean bias, NaN pixels.
+  cpu_baseline the CPU oracle (a bit-exact port of the reference's main-cpu.c path) timed on this host's cores
+               on a bounded sample of the same scene.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,59 +41,137 @@ sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 128 lanes x 2 x 2.4 GHz
 
+# flops per executed event (FMA = 2 flops; compares and selects not counted), DESIGN.md 5
+FLOPS = {"sphere_tests": 20,            # geomfunc.h:10-39: 3 sub, 2 dots (10), b*b - . + rr (3), sqrt, 2 add/sub
+         "triangle_tests_mt": 52,       # geomfunc.h:45-78: 2 cross, 4 dot, rcp, 3 mul, 1 add
+         "triangle_tests_planes": 32,   # triangle_planes_t: 4 dots of 3 (20), rcp, sub, mul, P (6), 2 add, 1 add
+         "bvh_nodes": 22,               # slab test: 6 sub, 6 mul, 10 min/max
+         "light_samples": 70,           # geomfunc.h:227-300 without the shadow scan
+         "plane_side_tests": 5,         # dot of 3 against the light's plane
+         "segment_near_tests": 21,      # 3 sub, dot, med3, 3 fma, dot, mul
+         "ball_point_tests": 8,         # 3 sub, dot of 3
+         "extension_rays": 120}         # shading of a closest hit, beside its primitive tests
+# a light point sampled once more for a binned ray (wf_trace_near): sqrt, 2 scales, 2 adds, sub, dot, rsq, scale
+FLOPS_RESAMPLED_POINT = 33
 
-def cpu_baseline(scene_name, cull_mode):
-    """Rank 0, N = 1 only.  oracle/ is used here as the timed CPU baseline and the flop counter."""
+
+def spawn_ranks(n):
+    """Started without a launcher: run the same command under torch.distributed.run, one rank per GPU.
+    Nothing in this process has touched the GPU yet."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def cpu_baseline(scene_name):
+    """Rank 0, N = 1 only.  oracle/ is used here as the timed CPU baseline and the reference's flop counter."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_binding as ob
     import pyptgpu as pt
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    # flops per path of the reference algorithm, counted on a 96x72 frame (serial, counting build)
+    # flops per path of the reference algorithm (full scans), counted on a 96x72 frame (serial, counting build)
     cw, ch = 96, 72
     sc = pt.LoadedScene(scene_name, cw, ch)
     ctr = ob.Counters()
-    t0 = time.perf_counter()
     ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle_counted(ctr, 1)
-    t_count = time.perf_counter() - t0
-    flops_per_path = ctr.flops() / ctr.paths
-    # the same count with the shadow-ray candidate sets the kernel uses (same image under SAFE)
-    culled = ob.Counters()
-    with ob.shadow_candidates(pt.shadow_candidates(sc, cull_mode)):
-        ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle_counted(culled, 1)
-    culled_flops_per_path = culled.flops() / culled.paths
-    # single thread = the reference's serial loop (main-cpu.c:61-62)
-    t0 = time.perf_counter()
-    ob.Render(sc, pt.seed_block(cw, ch)).pass_oracle(1, threads=1)
-    t_one = time.perf_counter() - t0
-    one = cw * ch / t_one / 1e6
+    # single thread = the reference's serial loop (main-cpu.c:61-62), at least ~1 s of it
+    t_one, passes_one = 0.0, 0
+    r = ob.Render(sc, pt.seed_block(cw, ch))
+    while t_one < 1.0 and passes_one < 64:
+        t0 = time.perf_counter()
+        r = r.pass_oracle(1, threads=1)
+        t_one += time.perf_counter() - t0
+        passes_one += 1
+    one = cw * ch * passes_one / t_one / 1e6
     # all threads, sized for ~10-20 s of wall time
     paths_target = max(one * 1e6 * threads * 12.0, cw * ch)
     scale = max(1, int((paths_target / (cw * ch)) ** 0.5))
     bw, bh = min(1024, cw * scale) // 8 * 8, min(768, ch * scale) // 8 * 8
+    spp = max(1, min(64, int(paths_target / (bw * bh))))
     scb = pt.LoadedScene(scene_name, bw, bh)
     t0 = time.perf_counter()
-    ob.Render(scb, pt.seed_block(bw, bh)).pass_oracle(1, threads=threads)
+    ob.Render(scb, pt.seed_block(bw, bh)).pass_oracle(spp, threads=threads)
     t_all = time.perf_counter() - t0
     return {
-        "value": bw * bh / t_all / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
-        "sample": f"{scene_name} {bw}x{bh} x 1 spp, {threads} OpenMP threads over rows, {t_all:.1f} s",
+        "value": bw * bh * spp / t_all / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
+        "sample": f"{scene_name} {bw}x{bh} x {spp} spp, {threads} OpenMP threads over rows, {t_all:.1f} s",
         "single_thread_value": one,
-        "single_thread_sample": f"{scene_name} {cw}x{ch} x 1 spp, serial loop as main-cpu.c, {t_one:.1f} s",
-    }, culled_flops_per_path, flops_per_path, {"reference": ctr.as_dict(), "with_candidate_sets": culled.as_dict()}
+        "single_thread_sample": f"{scene_name} {cw}x{ch} x {passes_one} spp, serial loop as main-cpu.c, {t_one:.1f} s",
+    }, ctr.flops() / ctr.paths, ctr.as_dict()
+
+
+def executed_work(pt, args, make_gpu, w, h):
+    """Counting build, reduced frame, same scene and options: events per path of what the kernel executes."""
+    scale = max(w / 256.0, h / 192.0, 1.0)
+    cw, ch = max(8, int(w / scale) // 8 * 8), max(8, int(h / scale) // 8 * 8)
+    passes = 2
+    sc = pt.LoadedScene(args.scene, cw, ch)
+    g = make_gpu(lib=pt.variant_path("count"))
+    g.set_scene(sc)
+    g.resize(cw, ch, pt.seed_block(cw, ch))
+    g.work_counters(reset=True)
+    g.render(passes)
+    g.finish()
+    work = g.work_counters()
+    li = g.launch_info()
+    g.close()
+    paths = work["paths"]
+    per_path = {k: v / paths for k, v in work.items()}
+    flops = sum(FLOPS[k] * per_path[k] for k in FLOPS)
+    # light points sampled beyond the light samples themselves = binned rays rebuilt when traced
+    flops += FLOPS_RESAMPLED_POINT * max(0.0, per_path["light_points"] - per_path["light_samples"])
+    return flops, per_path, f"{args.scene}.txt {cw}x{ch} x {passes} spp, counting build", li
+
+
+def image_error(pt, make_gpu, sc, seeds, w, h, spp):
+    """fast build (as benchmarked) against the strict build (= the reference, bit for bit) at equal seeds/spp."""
+    import numpy as np
+    imgs = {}
+    for name, math in (("fast", pt.MATH_FAST), ("strict", pt.MATH_STRICT)):
+        g = make_gpu(math=math, cull=(None if name == "fast" else pt.CULL_AUTO))
+        g.set_scene(sc)
+        g.resize(w, h, seeds)
+        g.render(spp)
+        g.finish()
+        imgs[name] = g.colors()
+        g.close()
+    a, b = imgs["fast"], imgs["strict"]
+    ok = np.isfinite(a).all(1) & np.isfinite(b).all(1)
+    d = a[ok].astype(np.float64) - b[ok]
+    mean = float(b[ok].astype(np.float64).mean())
+    return {"vs": "strict build (bit-exact with the reference's CPU path: tests/test_gpu_parity.py), same seeds",
+            "frame": f"{w}x{h}", "spp": spp,
+            "rmse": float(np.sqrt((d ** 2).mean())), "rel_rmse": float(np.sqrt((d ** 2).mean()) / mean),
+            "mean_bias": float(d.mean()), "mean_rel_bias": float(d.mean() / mean),
+            "mean_rel_bias_rgb": (d.mean(0) / b[ok].astype(np.float64).mean(0)).tolist(),
+            "max_abs": float(np.abs(d).max()), "mean_radiance_strict": mean,
+            "nan_pixels_fast": int((~np.isfinite(a).all(1)).sum()), "nan_pixels_strict": int((~np.isfinite(b).all(1)).sum())}
+
+
+def committed_profile(workload_key):
+    """Per-pass PMC figures of a committed rocprofv3 run of this workload (profiles/r02/pmc_summary.json)."""
+    try:
+        return json.load(open(os.path.join(REPO, "profiles", "r02", "pmc_summary.json"))).get(workload_key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--passes", type=int, default=32,
+    ap.add_argument("--passes", type=int, default=64,
                     help="progressive passes per step (the reference's frame after warm-up is 0.5 s of passes, "
-                         "main-gpu.c:774-794: hundreds at this rate)")
+                         "main-gpu.c:774-794: hundreds at this rate); 16 steps x 64 = the 1 024 spp of BASELINE config 2")
     ap.add_argument("--scene", default="cornell")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=768)
-    ap.add_argument("--kernel", default="wavefront", choices=["mega", "wavefront"])
+    ap.add_argument("--kernel", default="auto", choices=["auto", "mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
     ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "ball", "auto"],
@@ -94,7 +182,13 @@ def main():
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-count", action="store_true", help="skip the counting-build run (roofline is then null)")
+    ap.add_argument("--no-image-error", action="store_true", help="skip the fast-vs-strict comparison")
+    ap.add_argument("--key-only", action="store_true", help="render one pass and print the workload key (scripts/profile_r02.sh)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))   # before anything touches the GPU
 
     import torch
     import multigpu
@@ -109,20 +203,23 @@ def main():
         raise SystemExit("bench.py needs a GPU: the radiance path has no CPU fallback")
     local_rank %= torch.cuda.device_count()  # rehearsals may put several ranks on one GPU (gloo only)
     torch.cuda.set_device(local_rank)
-    # The library's four region streams are created BEFORE the process group: HIP spreads streams
-    # over GPU_MAX_HW_QUEUES (4) hardware queues in creation order, and with RCCL's streams in
-    # first the regions double up on a queue and a pass runs as slowly as with one stream (+14 %).
     w, h = args.width, args.height
     sc = pt.LoadedScene(args.scene, w, h)
     seeds = pt.seed_block(w, h, rank)
-    g = pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
-               kernel=pt.KERNEL_WAVEFRONT if args.kernel == "wavefront" else pt.KERNEL_MEGA,
-               math=pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT, streams=args.streams,
-               work_queue={"auto": 2, "on": 1, "off": 0}[args.work_queue],
-               passes_per_launch=args.passes_per_launch,
-               shadow_cull={"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
-                            "ball": pt.CULL_BALL, "auto": pt.CULL_AUTO}[args.cull])
-    cull = args.cull if args.cull != "auto" else ("enclosed" if args.math == "fast" else "safe")
+    culls = {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
+             "ball": pt.CULL_BALL, "auto": pt.CULL_AUTO}
+
+    def make_gpu(math=None, cull=None, lib=None):
+        return pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,
+                      kernel={"auto": pt.KERNEL_AUTO, "mega": pt.KERNEL_MEGA, "wavefront": pt.KERNEL_WAVEFRONT}[args.kernel],
+                      math=(pt.MATH_FAST if args.math == "fast" else pt.MATH_STRICT) if math is None else math,
+                      streams=args.streams, work_queue={"auto": 2, "on": 1, "off": 0}[args.work_queue],
+                      passes_per_launch=args.passes_per_launch,
+                      shadow_cull=culls[args.cull] if cull is None else cull, lib=lib)
+
+    # The library's region streams are created BEFORE the process group: HIP spreads streams over
+    # GPU_MAX_HW_QUEUES (4) hardware queues in creation order.
+    g = make_gpu()
     g.set_scene(sc)
     g.resize(w, h, seeds)
     dist = None
@@ -141,6 +238,15 @@ def main():
         g.finish()
         torch.cuda.synchronize()
 
+    if args.key_only:
+        g.render(1)
+        g.finish()
+        li = g.launch_info()
+        names = {v: k for k, v in culls.items() if k != "auto"}
+        print(f"{args.scene}-{w}x{h}-{args.integrator}-{args.math}-{names[li['shadow_cull']]}-"
+              f"{'wavefront' if li['kernel'] == pt.KERNEL_WAVEFRONT else 'mega'}")
+        g.close()
+        return
     for _ in range(args.warmup):
         g.render_timed(args.passes)
     if dist is not None:
@@ -169,87 +275,87 @@ def main():
     if os.environ.get("PT_BENCH_TRACE"):
         print(f"[rank {rank}] render {1e3 * (t1 - t0):.2f} ms, all-reduce {1e3 * (t2 - t1):.2f}, repack {1e3 * (t3 - t2):.2f}, "
               f"barrier {1e3 * (t0 + elapsed - t3):.2f}", file=sys.stderr, flush=True)
+    ranks_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ranks_seen = dist.get_world_size()   # from the communicator, not from the command line
 
-    paths_per_launch = w * h * args.passes
-    total_paths = paths_per_launch * args.steps * world
+    paths_per_step = w * h * args.passes
+    total_paths = paths_per_step * args.steps * world
     value = total_paths / elapsed / 1e6
 
     if rank == 0:
         pixels = g.pixels()
-        baseline, flops_per_path, ref_flops_per_path, counters = (None, None, None, None)
-        if world == 1 and not args.no_cpu:
-            baseline, flops_per_path, ref_flops_per_path, counters = cpu_baseline(
-                args.scene, {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
-                             "ball": pt.CULL_BALL}[cull])
-        # One step = args.passes passes.  With the work queue a step is ONE launch (rocprof's AverageNs
-        # = avg_step_event_ms).  Without it, with S region streams, a pass is S concurrent launches of
-        # the same kernel (each 1/S of the tiles); the HIP events bracket the whole step on the
-        # library's stream (fork/join), so the per-launch figure below is step time / sequential
-        # launch groups (see DESIGN.md "Measurement").
+        li = g.launch_info()
+        cull_names = {v: k for k, v in culls.items() if k != "auto"}
+        kernel_name = "radiance_%s_kernel" % ("wavefront" if li["kernel"] == pt.KERNEL_WAVEFRONT else "mega")
+        instance = ("fast" if li["math"] == pt.MATH_FAST else "strict") + {0: "", 1: "_bvh", 2: "_hyb", 3: "_ball"}[li["instance"]]
         avg_step_ms = sum(launch_ms) / len(launch_ms)
-        n_tiles = ((w + 7) // 8) * ((h + 7) // 8)
-        info = g.scene_info()
-        # the library's own rule (ptgpu.h, PTGPU_OPT_WORK_QUEUE): one launch per step when it applies
-        work = info["primitives"] * (1 + info["lights"])
-        unit_passes = min(max((4096 + work - 1) // max(work, 1), 1), 16, args.passes)
-        queue = args.kernel == "wavefront" and (args.work_queue == "on" or (
-            args.work_queue == "auto" and args.integrator == "pt" and n_tiles >= 2048 and unit_passes * work >= 512))
-        ppl = args.passes if queue else (args.passes_per_launch or (1 if (args.streams > 1 and n_tiles >= 2048) else 8))
-        groups_per_step = (args.passes + ppl - 1) // ppl
-        # HBM bytes per pass from the committed PMC run of this workload (separate rocprofv3 --pmc
-        # passes, profiles/traffic.json); null for any other workload.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            if (args.scene, w, h, args.kernel, args.math, cull) == ("cornell", 1024, 768, "wavefront", "fast", tj.get("cull", "off")):
-                traffic = tj["bytes_per_pass"] * args.passes
-        except (OSError, ValueError, KeyError):
-            pass
+        launches_per_step = 1 if li["work_queue"] else (args.passes + li["passes_per_launch"] - 1) // max(li["passes_per_launch"], 1)
+        workload_key = (f"{args.scene}-{w}x{h}-{args.integrator}-{args.math}-{cull_names[li['shadow_cull']]}-"
+                        f"{'wavefront' if li['kernel'] == pt.KERNEL_WAVEFRONT else 'mega'}")
+
+        baseline = ref_flops_per_path = ref_counters = None
+        if world == 1 and not args.no_cpu:
+            baseline, ref_flops_per_path, ref_counters = cpu_baseline(args.scene)
         roofline = None
-        if flops_per_path is not None:
-            # primitive tests of the extension rays under a full scan: R x (20 per sphere + 52 per triangle)
-            ref_ctr = counters["reference"]
-            o = sc.objects
-            n_sph, n_tri = int((o["type"] == 0).sum()), int((o["type"] == 1).sum())
-            ext_test_flops_per_path = ref_ctr["extension_rays"] * (20 * n_sph + 52 * n_tri) / ref_ctr["paths"]
-            achieved = flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12
-            roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
-                        "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE + WRITE_SIZE), algorithmic %d" % (52 * w * h * args.passes),
-                        "kernel": f"radiance_{args.kernel}_kernel ({args.math})",
-                        "avg_step_event_ms": avg_step_ms,
-                        "avg_launch_group_ms": avg_step_ms / groups_per_step,
-                        "launch_groups_per_step": groups_per_step,
-                        "concurrent_launches_per_group": 1 if queue else (args.streams if ppl == 1 or args.streams > 1 else 1),
-                        "work_queue": bool(queue),
-                        "passes_per_launch": ppl,
+        if world == 1 and not args.no_count:
+            flops_per_path, per_path, count_sample, count_li = executed_work(pt, args, make_gpu, w, h)
+            achieved = flops_per_path * paths_per_step / (avg_step_ms * 1e-3) / 1e12
+            prof = committed_profile(workload_key)
+            issued = None
+            traffic = None
+            if prof:
+                # FP32 VALU work the hardware issued per pass (wave instructions x 64 lanes x active share)
+                fl = (2 * prof["SQ_INSTS_VALU_FMA_F32"] + prof["SQ_INSTS_VALU_ADD_F32"] + prof["SQ_INSTS_VALU_MUL_F32"]
+                      + prof["SQ_INSTS_VALU_TRANS_F32"]) * 64 * prof["active_lane_fraction"] / prof["passes"]
+                tf = fl * args.passes / (avg_step_ms * 1e-3) / 1e12
+                issued = {"tflops": tf, "frac": tf / PEAK_FP32_VALU_TFLOPS, "flops_per_path": fl / (w * h),
+                          "active_lane_fraction": prof["active_lane_fraction"],
+                          "occupancy_waves_per_cu": prof.get("occupancy_waves_per_cu"),
+                          "source": "profiles/r02/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes) x this run's step time" % workload_key}
+                if prof.get("FETCH_SIZE_bytes_per_pass") is not None and prof.get("WRITE_SIZE_bytes_per_pass") is not None:
+                    traffic = (prof["FETCH_SIZE_bytes_per_pass"] + prof["WRITE_SIZE_bytes_per_pass"]) * args.passes
+            roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "HBM bytes per step (PMC FETCH_SIZE + WRITE_SIZE of the committed run), algorithmic %d" % (52 * w * h * args.passes),
+                        "kernel": f"ptk_{instance}::{kernel_name}",
+                        "avg_step_event_ms": avg_step_ms, "launches_per_step": launches_per_step,
+                        "avg_launch_ms": avg_step_ms / launches_per_step,
+                        "concurrent_region_streams": li["regions"],
+                        "work_queue": bool(li["work_queue"]), "unit_passes": li["unit_passes"],
+                        "passes_per_launch": li["passes_per_launch"], "lds_bytes_staged": li["lds_bytes"],
                         "algorithmic_flops_per_path": flops_per_path,
-                        "algorithm": f"reference integrator with shadow-ray candidate sets ({cull}); extension rays counted "
-                                     "as full scans although the fast build walks a hierarchy for them (fewer tests): "
-                                     "frac_without_extension_tests is the same figure with those tests left out",
-                        "frac_without_extension_tests": (flops_per_path - ext_test_flops_per_path) * paths_per_launch
-                                                        / (avg_step_ms * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS,
+                        "algorithm": "work the kernel executes, counted by the kernel (counting build) per active lane: "
+                                     "events per path x flops per event",
+                        "executed_events_per_path": per_path, "flops_per_event": FLOPS, "count_sample": count_sample,
+                        "count_sample_launch_matches": {k: count_li[k] == li[k] for k in ("kernel", "instance", "shadow_cull", "ray_bins")},
+                        "valu_fp32_issued": issued,
                         "reference_equivalent_flops_per_path": ref_flops_per_path,
-                        "reference_equivalent_tflops": ref_flops_per_path * paths_per_launch / (avg_step_ms * 1e-3) / 1e12,
-                        "paths_per_step": paths_per_launch,
-                        "hbm_algorithmic_bytes_per_pass": 52 * w * h}
+                        "reference_equivalent_tflops": (ref_flops_per_path * paths_per_step / (avg_step_ms * 1e-3) / 1e12)
+                                                       if ref_flops_per_path else None,
+                        "reference_equivalent_note": "the reference's brute-force scans (SURVEY 8-d formula on the CPU oracle's "
+                                                     "counters); NOT what frac is built from",
+                        "paths_per_step": paths_per_step, "hbm_algorithmic_bytes_per_pass": 52 * w * h}
+        err = None
+        if world == 1 and args.math == "fast" and not args.no_image_error:
+            err = image_error(pt, make_gpu, sc, seeds, w, h, min(16, args.passes))
         line = {
-            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world,
+            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "scene file data/scenes/%s.txt (the reference's own), rand()-compatible seeds" % args.scene,
-            "config": {"workload": f"{args.scene}.txt {w}x{h}, {args.passes} passes/step, "
-                                   f"{args.integrator} integrator, {args.kernel} kernel, {args.math} math, shadow cull {cull}",
+            "config": {"workload": f"{args.scene}.txt {w}x{h}, {args.steps * args.passes} spp timed ({args.passes} passes/step), "
+                                   f"{args.integrator} integrator, {kernel_name} ({instance}), shadow cull {cull_names[li['shadow_cull']]}",
                        "spp_timed": args.steps * args.passes, "spp_per_s": args.steps * args.passes * world / elapsed,
-                       "parallelism": f"passes split over {world} GPU(s) by seed block + 1 all-reduce"},
-            "roofline": roofline, "cpu_baseline": baseline,
+                       "parallelism": f"passes split over {world} GPU(s) by seed block + 1 all-reduce of the float4 sample buffer "
+                                      f"per {args.steps * args.passes} passes per rank"},
+            "workload_key": workload_key, "roofline": roofline, "cpu_baseline": baseline, "image_error": err,
             "speedup_vs_cpu_all_cores": (value / world / baseline["value"]) if baseline else None,
             "speedup_vs_cpu_single_thread": (value / world / baseline["single_thread_value"]) if baseline else None,
-            "oracle_counters_sample": counters,
+            "reference_counters_sample": ref_counters,
             "nan_pixels": int((pixels == 0x80000000).sum()),
         }
         print(json.dumps(line), flush=True)

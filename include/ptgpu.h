@@ -275,6 +275,8 @@ enum {
     PTGPU_WORK_SHADOW_RAYS,        /* any-hit rays traced                                            */
     PTGPU_WORK_RNG_DRAWS,          /* GetRandom calls (integer work)                                 */
     PTGPU_WORK_PATHS,
+    PTGPU_WORK_NODE_LANE_SLOTS,    /* 64 per wave and node step: with BVH_NODES, the lane utilisation of the walks */
+    PTGPU_WORK_PRIM_LANE_SLOTS,    /* 64 per wave and primitive test: likewise, against the three test counters   */
     PTGPU_WORK_SLOTS = 16
 };
 int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters /* [PTGPU_WORK_SLOTS] */, int reset);

@@ -288,7 +288,9 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.cbounds = c->d_cbounds;
     const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
     // the fast build's own translation units read triangles in plane form (radiance_device.inc)
+#if !(defined(PT_EXACT) && (PT_EXACT & 16)) // (measurement build with Moeller-Trumbore in the fast kernels: scripts/bias_bisect.sh)
     if (c->math == PTGPU_MATH_FAST && !use_bvh) p.sprims = c->d_sprims_planes;
+#endif
     if (use_bvh) { // the hierarchy replaces the candidate sets
         p.smask = nullptr;
         p.ball_groups = 0;

@@ -5,7 +5,7 @@
  *
  *   ptcli [<useGPU> <forceWorkSize> <kernel file> <width> <height> <scene file>]
  *         [--spp N] [--out image.ppm] [--integrator pt|dl] [--math fast|strict]
- *         [--kernel wavefront|mega] [--models DIR] [--device N] [--quiet]
+ *         [--kernel wavefront|mega] [--models DIR] [--device N] [--gpus N] [--quiet]
  *
  * The six positional arguments are the reference's (main-gpu.c:924-930); with none, its defaults
  * are used (1 0 path-tracing.cl 800 600 scenes/stacked-spheres.txt).  <useGPU> and
@@ -13,14 +13,28 @@
  * shape); a <kernel file> named ray-tracing.cl selects the direct-lighting integrator, anything
  * else the path tracer - the reference selects the integrator by which .cl file it builds.
  * Errors print to stderr and exit(-1) like the reference.
+ *
+ * --gpus N (no counterpart in the reference, which drives one device: main-gpu.c:398-404): ONE process, N
+ * contexts on devices <device> .. <device>+N-1.  The passes are split by disjoint seed streams - GPU g takes
+ * the g-th block of 2*W*H rand() outputs and renders ceil(spp / N) passes into its own sample buffer - and
+ * the buffers are summed in place with one RCCL all-reduce over xGMI (ncclCommInitAll + ncclAllReduce on
+ * ptgpu_colors_device_ptr / ptgpu_stream), scaled by 1/N and re-packed on the first device.  A NaN sample
+ * (the reference's black firefly) poisons its pixel's sum: the combined image shows the union
+ * of every GPU's NaN pixels, as one GPU rendering all the passes from one seed stream would show its own.
+ * --gpus 1 goes through the same code with a communicator of one (rehearsal on a one-GPU box).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <sys/time.h>
 
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
 #include "ptgpu.h"
 #include "pthost.h"
+
+#define MAX_GPUS 64
 
 static double wall_clock(void) { /* reference time-utils.c:7-12 */
     struct timeval t;
@@ -33,10 +47,84 @@ static void die_gpu(const char *what) {
     exit(-1);
 }
 
+static void die_hip(const char *what, hipError_t e) {
+    fprintf(stderr, "%s: %s\n", what, hipGetErrorString(e));
+    exit(-1);
+}
+
+static void die_rccl(const char *what, ncclResult_t r) {
+    fprintf(stderr, "%s: %s\n", what, ncclGetErrorString(r));
+    exit(-1);
+}
+
+/* The whole multi-GPU render (see the header comment).  Fills `pixels` with the combined image and returns
+ * the passes rendered in total (N * ceil(spp / N)). */
+static int render_on_gpus(int n_gpus, int first_device, int integrator, int math, int kernel, int cull,
+                          const pthost_scene *sc, int width, int height, int spp, uint32_t *pixels, int quiet) {
+    const size_t n = (size_t)width * height;
+    ptgpu_ctx *ctx[MAX_GPUS];
+    ncclComm_t comm[MAX_GPUS];
+    int devs[MAX_GPUS];
+    const int per_gpu = (spp + n_gpus - 1) / n_gpus;
+    uint32_t *seeds = malloc(sizeof(uint32_t) * 2 * n);
+    if (!seeds) {
+        fprintf(stderr, "out of memory\n");
+        exit(-1);
+    }
+    for (int g = 0; g < n_gpus; ++g) {
+        devs[g] = first_device + g;
+        if (ptgpu_create(&ctx[g], devs[g], integrator)) die_gpu("Failed to create the device context");
+        if (ptgpu_set_option(ctx[g], PTGPU_OPT_MATH, math) || ptgpu_set_option(ctx[g], PTGPU_OPT_KERNEL, kernel) ||
+            ptgpu_set_option(ctx[g], PTGPU_OPT_SHADOW_CULL, cull))
+            die_gpu("Failed to set an option");
+        if (ptgpu_set_scene(ctx[g], sc->objects, sc->object_count, sc->light_count, sc->materials,
+                            sc->scene.material_count, &sc->scene))
+            die_gpu("Failed to upload the scene");
+        if (ptgpu_set_camera(ctx[g], &sc->camera)) die_gpu("Failed to upload the camera");
+        pthost_seed_block(seeds, 2 * n, (uint64_t)g * 2 * n); /* disjoint seed streams */
+        if (ptgpu_resize(ctx[g], width, height, seeds)) die_gpu("Failed to create the image buffers");
+    }
+    free(seeds);
+    /* contexts (and their streams) first, the communicators after them: INTEGRATION.md, "Multi-GPU" */
+    ncclResult_t r = ncclCommInitAll(comm, n_gpus, devs);
+    if (r != ncclSuccess) die_rccl("ncclCommInitAll", r);
+
+    /* every GPU's passes are enqueued before any of them is waited for */
+    for (int done = 0; done < per_gpu; done += 64) {
+        const int batch = per_gpu - done < 64 ? per_gpu - done : 64;
+        for (int g = 0; g < n_gpus; ++g)
+            if (ptgpu_render(ctx[g], done, batch)) die_gpu("Failed to enqueue work");
+    }
+    /* the one collective of the path: sum of the float4 sample buffers, in place, each on its context's stream */
+    r = ncclGroupStart();
+    if (r != ncclSuccess) die_rccl("ncclGroupStart", r);
+    for (int g = 0; g < n_gpus; ++g) {
+        void *colors = NULL, *stream = NULL;
+        if (ptgpu_colors_device_ptr(ctx[g], &colors) || ptgpu_stream(ctx[g], &stream)) die_gpu("Failed to get the sample buffer");
+        hipError_t e = hipSetDevice(devs[g]);
+        if (e != hipSuccess) die_hip("hipSetDevice", e);
+        r = ncclAllReduce(colors, colors, (size_t)PTGPU_COLOR_STRIDE_FLOATS * n, ncclFloat, ncclSum, comm[g], (hipStream_t)stream);
+        if (r != ncclSuccess) die_rccl("ncclAllReduce", r);
+    }
+    r = ncclGroupEnd();
+    if (r != ncclSuccess) die_rccl("ncclGroupEnd", r);
+    for (int g = 0; g < n_gpus; ++g)
+        if (ptgpu_finish(ctx[g])) die_gpu("Failed to finish");
+    /* equal pass counts: the mean of the per-GPU means is the mean over all passes */
+    if (ptgpu_scale_and_repack(ctx[0], 1.0f / (float)n_gpus)) die_gpu("Failed to re-pack the image");
+    if (ptgpu_read_pixels(ctx[0], pixels)) die_gpu("Failed to read the pixel buffer");
+    if (!quiet) fprintf(stderr, "%d GPU(s) x %d passes, one all-reduce of %zu floats\n", n_gpus, per_gpu, (size_t)PTGPU_COLOR_STRIDE_FLOATS * n);
+    for (int g = 0; g < n_gpus; ++g) {
+        ncclCommDestroy(comm[g]);
+        ptgpu_destroy(ctx[g]);
+    }
+    return per_gpu * n_gpus;
+}
+
 int main(int argc, char *argv[]) {
     const char *scene_name = "scenes/stacked-spheres.txt", *kernel_file = "path-tracing.cl";
     const char *out_path = NULL, *model_dir = NULL;
-    int width = 800, height = 600, spp = 64, device = 0, quiet = 0;
+    int width = 800, height = 600, spp = 64, device = 0, quiet = 0, gpus = 0;
     int integrator = -1, math = PTGPU_MATH_FAST, kernel = PTGPU_KERNEL_AUTO, cull = PTGPU_CULL_AUTO;
 
     int npos = 0;
@@ -48,6 +136,7 @@ int main(int argc, char *argv[]) {
         else if (!strcmp(a, "--out") && v) { out_path = v; ++i; }
         else if (!strcmp(a, "--models") && v) { model_dir = v; ++i; }
         else if (!strcmp(a, "--device") && v) { device = atoi(v); ++i; }
+        else if (!strcmp(a, "--gpus") && v) { gpus = atoi(v); ++i; }
         else if (!strcmp(a, "--integrator") && v) { integrator = !strcmp(v, "dl") ? PT_INTEGRATOR_DL : PT_INTEGRATOR_PT; ++i; }
         else if (!strcmp(a, "--math") && v) { math = !strcmp(v, "strict") ? PTGPU_MATH_STRICT : PTGPU_MATH_FAST; ++i; }
         else if (!strcmp(a, "--kernel") && v) {
@@ -64,7 +153,7 @@ int main(int argc, char *argv[]) {
             fprintf(stderr, "Usage: %s [<use CPU/GPU device> <workgroup size> <kernel file name> <window width> "
                             "<window height> <scene file>] [--spp N] [--out image.ppm] [--integrator pt|dl] "
                             "[--math fast|strict] [--kernel auto|wavefront|mega] [--cull auto|off|safe|tight|enclosed|ball] [--models DIR] "
-                            "[--device N]\n", argv[0]);
+                            "[--device N] [--gpus N]\n", argv[0]);
             exit(-1);
         } else if (npos < 6) pos[npos++] = a;
     }
@@ -92,6 +181,31 @@ int main(int argc, char *argv[]) {
     if (!seeds || !pixels) {
         fprintf(stderr, "out of memory\n");
         exit(-1);
+    }
+    if (gpus < 0 || gpus > MAX_GPUS) {
+        fprintf(stderr, "--gpus must be 1..%d\n", MAX_GPUS);
+        exit(-1);
+    }
+    if (gpus > 0) { /* passes split over GPUs by seed stream, one RCCL all-reduce (header comment) */
+        const double t0 = wall_clock();
+        const int rendered = render_on_gpus(gpus, device, integrator, math, kernel, cull, &sc, width, height, spp, pixels, quiet);
+        const double dt = wall_clock() - t0;
+        printf("%s: %d passes on %d GPU(s), %dx%d, %.3f s, %.2f Mpaths/s\n", sc.title, rendered, gpus, width, height, dt,
+               (double)n * rendered / dt / 1e6);
+        char multi_name[300];
+        if (!out_path) {
+            pthost_snapshot_name(multi_name, sizeof multi_name, sc.title, rendered, dt);
+            out_path = multi_name;
+        }
+        if (pthost_write_ppm(out_path, pixels, width, height)) {
+            fprintf(stderr, "%s\n", pthost_last_error());
+            exit(-1);
+        }
+        if (!quiet) fprintf(stderr, "wrote %s\n", out_path);
+        pthost_free_scene(&sc);
+        free(seeds);
+        free(pixels);
+        return 0;
     }
     pthost_seed_block(seeds, 2 * n, 0);
 

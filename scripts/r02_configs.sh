@@ -1,0 +1,22 @@
+#!/bin/bash
+# BASELINE configs 3, 4, 5 (+ cornell with the other candidate-set modes): one bench line and one rocprofv3
+# evidence set each (run on the GPU box via gpurun).  Results under gpurun_out/bench_r02 and gpurun_out/prof_r02.
+mkdir -p gpurun_out/bench_r02
+run() { # name, bench args...
+  local name=$1; shift
+  echo "== bench $name"
+  timeout -k 10 300 python3 bench.py "$@" > gpurun_out/bench_r02/$name.json 2> gpurun_out/bench_r02/$name.err
+  rc=$?; echo "rc=$rc"; case $rc in 124|134|137|139) exit $rc;; esac
+}
+prof() { echo "== profile $*"; timeout -k 10 400 scripts/profile_r02.sh "$@" > /dev/null 2>&1; rc=$?; echo "rc=$rc"; case $rc in 124|134|137|139) exit $rc;; esac; }
+for cfg in "materials_pt --scene materials" "materials_dl --scene materials --integrator dl" "caustic_pt --scene caustic" \
+           "caustic_dl --scene caustic --integrator dl" "obj-model_pt --scene obj-model" "obj-model-bunny_pt --scene obj-model-bunny" \
+           "cornell-large_4k_pt --scene cornell-large --width 3840 --height 2160"; do
+  set -- $cfg; name=$1; shift
+  run $name "$@"
+  prof "$@"
+done
+run cornell_cull_safe --cull safe --no-cpu
+run cornell_cull_tight --cull tight --no-cpu
+run cornell_cull_ball --cull ball --no-cpu
+run cornell_strict --math strict --no-cpu --steps 4 --passes 16

@@ -329,7 +329,7 @@ def test_fast_build_within_calibrated_floor(case, kernel):
     assert agree >= 0.999, f"{name}: RNG state agreement after pass 1 = {agree:.5f}"
     # (2)-(4) image error at the calibrated spp
     cpu = cpu1.pass_oracle(spp - 1, threads=8)
-    colors, pixels, _ = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_FAST)
+    colors, pixels, sd_final = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_FAST)
     nan_g, nan_c = np.isnan(colors).any(1), np.isnan(cpu.colors).any(1)
     ok = ~(nan_g | nan_c)
     d = (colors[ok].astype(np.float64) - cpu.colors[ok])
@@ -342,7 +342,15 @@ def test_fast_build_within_calibrated_floor(case, kernel):
     rmse_trim = np.sqrt(e2[: int(len(e2) * 0.995)].mean())
     assert rmse_trim <= 2 * floor_rmse, (rmse_trim, floor_rmse)
     assert rmse <= max(2 * floor_rmse, 2e-3 * float(cpu.colors[ok].mean())), (rmse, floor_rmse)
-    assert share <= 2 * floor_share + 0.05
+    if floor_share <= 0.45:
+        assert share <= 2 * floor_share + 0.05
+    else:
+        # (cornell.txt: half of the pixels already differ between the two CPU builds - a pixel is 8 x ~250
+        # shadow decisions, and a flipped one draws nothing from the RNG - so twice that share cannot fail.)
+        # Stated instead: no more than the floor's share + 10 points, and no drift of the mean radiance
+        # beyond 2e-3 of it (the differences are flipped decisions, not a bias)
+        assert share <= floor_share + 0.10
+        assert abs(float(d.mean())) <= 2e-3 * float(cpu.colors[ok].mean())
     assert abs(int(nan_g.sum()) - int(nan_c.sum())) <= max(2, 0.002 * w * h)
     # 8-bit image: the bulk of the pixels is identical
     assert (pixels == cpu.pixels).mean() > 0.5
@@ -547,6 +555,55 @@ def test_full_size_properties_cornell_1024x768():
         q.close()
 
 
+def _fast_against_strict(w, h, spp, cull):
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    out = []
+    for math, c in ((pt.MATH_FAST, cull), (pt.MATH_STRICT, pt.CULL_SAFE)):
+        g = pt.Gpu(0, 0, math=math, shadow_cull=c)
+        g.set_scene(sc)
+        g.resize(w, h, seeds)
+        g.render(spp)
+        g.finish()
+        out.append(g.colors())
+        g.close()
+    fast, strict = out
+    ok = np.isfinite(fast).all(1) & np.isfinite(strict).all(1)
+    d = fast[ok].astype(np.float64) - strict[ok]
+    bias = d.mean(0) / strict[ok].astype(np.float64).mean(0)
+    rel_rmse = float(np.sqrt((d ** 2).mean()) / strict[ok].mean())
+    nan = (int((~np.isfinite(fast).all(1)).sum()), int((~np.isfinite(strict).all(1)).sum()))
+    blocks = None
+    if w % 8 == 0 and h % 8 == 0:
+        a = np.where(ok[:, None], fast, 0).reshape(h // 8, 8, w // 8, 8, 3).astype(np.float64).mean((1, 3, 4))
+        b = np.where(ok[:, None], strict, 0).reshape(h // 8, 8, w // 8, 8, 3).astype(np.float64).mean((1, 3, 4))
+        blocks = np.abs(a - b) / np.maximum(b, 1e-3)
+    return bias, rel_rmse, nan, blocks
+
+
+@pytest.mark.parametrize("size", [(256, 192, 64), (1024, 768, 4)], ids=["256x192x64", "1024x768x4"])
+def test_headline_build_has_no_bias_beyond_its_candidate_sets(size):
+    """BASELINE config 2's scene at sizes that mean something: the benchmarked build (fast math, ENCLOSED
+    sets) against the strict build, which is the reference bit for bit (goldens, oracle).  Stated tolerances:
+      fast math alone (SAFE sets = the reference's algorithm): |mean bias| <= 1e-4 of the radiance per channel
+        (measured 2e-6 .. 7e-6; the one-sided 2.4e-4 that the plain v_sqrt_f32 gave the sphere test is what
+        this pins, radiance_device.inc f_sqrt_refined);
+      ENCLOSED sets on top: one-signed, 0 .. +3e-4 per channel (measured +0.7e-4 .. +1.4e-4: the acne of
+        the wall spheres it takes out of the shadow scans, geomfunc.h:10-39; DESIGN.md 4.3);
+      relative RMSE <= 5 % at these sample counts (flipped decisions swap whole samples: noise, measured
+        1.8 % and 2.8 %); 8x8-block means: 99 % of the blocks within 1.5 %, mean deviation <= 0.3 %;
+      NaN pixels (the reference's black fireflies) within 2 of each other."""
+    w, h, spp = size
+    bias, rel_rmse, nan, blocks = _fast_against_strict(w, h, spp, pt.CULL_SAFE)
+    print(f"fast + SAFE vs strict {w}x{h}x{spp}: bias {bias}, rel rmse {rel_rmse:.4f}, nan {nan}")
+    assert (np.abs(bias) <= 1e-4).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
+    bias, rel_rmse, nan, blocks = _fast_against_strict(w, h, spp, pt.CULL_ENCLOSED)
+    print(f"fast + ENCLOSED vs strict {w}x{h}x{spp}: bias {bias}, rel rmse {rel_rmse:.4f}, nan {nan}, "
+          f"blocks p99 {np.quantile(blocks, .99):.4f} mean {blocks.mean():.5f}")
+    assert (bias >= -0.5e-4).all() and (bias <= 3e-4).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
+    assert np.quantile(blocks, .99) <= 0.015 and blocks.mean() <= 3e-3
+
+
 def test_c_host_cli_end_to_end(tmp_path):
     """The headless C host (ptcli = main-gpu.c's main()/updateRendering() over the C-ABI) renders a
     scene file to a PPM whose bytes are the oracle's packed pixels (strict build), rows bottom-up
@@ -572,6 +629,29 @@ def test_c_host_cli_end_to_end(tmp_path):
     # bad arguments: print-and-exit(-1) like the reference
     bad = subprocess.run(cmd[:6] + ["/nonexistent.txt"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "Failed to open file" in bad.stderr
+
+
+def test_c_host_gpus_goes_through_rccl_and_a_group_of_one_changes_nothing(tmp_path):
+    """ptcli --gpus N: one process, N contexts, seed blocks, ONE ncclAllReduce of the float4 sample buffers
+    (plain C over librccl).  The GPU box has one device: N = 1 runs every call of the N > 1 path
+    (ncclCommInitAll, grouped all-reduce on the context's stream, scale + re-pack) and must give the
+    plain run's image byte for byte; asking for a second device must fail cleanly."""
+    import os
+    import subprocess
+    from conftest import REPO
+    w, h, spp = 72, 48, 6
+    base = [os.path.join(REPO, "path-tracer_amd", "ptcli"), "1", "0", "path-tracing.cl", str(w), str(h),
+            os.path.join(REPO, "data", "scenes", "cornell-large.txt"), "--spp", str(spp), "--models",
+            os.path.join(REPO, "data"), "--quiet"]
+    for math in ("strict", "fast"):
+        a, b = tmp_path / f"plain_{math}.ppm", tmp_path / f"rccl_{math}.ppm"
+        r1 = subprocess.run(base + ["--math", math, "--out", str(a)], capture_output=True, text=True, timeout=120)
+        r2 = subprocess.run(base + ["--math", math, "--out", str(b), "--gpus", "1"], capture_output=True, text=True, timeout=180)
+        assert r1.returncode == 0 and r2.returncode == 0, (r1.stderr, r2.stderr)
+        assert "%d passes on 1 GPU(s)" % spp in r2.stdout
+        assert a.read_bytes() == b.read_bytes()
+    many = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=120)
+    assert many.returncode != 0 and "device" in many.stderr.lower()
 
 
 def test_checkpoint_resume_is_bit_identical(tmp_path):

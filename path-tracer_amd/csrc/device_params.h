@@ -99,6 +99,10 @@ struct PtDeviceParams {
     int sg_sph, sg_tri;   // sphere / triangle groups in sprims
     int n_sph_real;       // spheres before the fillers of the sphere section (full scans stop there)
     int mw_sph, mw_tri;   // mask words per light for each
+    // > 0 (only when mw_sph == mw_tri == 1): smask continues with a range table - level k, entry i, at
+    // smask[(k * n_lights + i) * 2 ..] = union of the sets of lights i .. i + 2^k - 1 (level 0 = the sets
+    // themselves); the union over any range of lights is the OR of two entries of one level
+    int smask_levels;
     // triangle clusters (fast build, TIGHT sets): n_clusters == 0 switches the ray binning off
     const unsigned long long *cmask;  // (1 + n_clusters) x mw_tri words: row 0 = triangle groups in no
                                       // cluster, row 1 + c = groups of cluster c

@@ -112,7 +112,7 @@ struct ptgpu_ctx {
     int n_hnodes = 0;
     uint32_t lds_fast_hyb = 0;
     uint32_t lds_bvh = 0, lds_bvh_nodes = 0; // whole block + lights; nodes + lights (when the block does not fit)
-    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0;
+    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0, smask_levels = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
     uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
     bool have_scene = false, have_camera = false;
@@ -280,6 +280,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.sg_tri = c->sg_tri;
     p.mw_sph = c->mw_sph;
     p.mw_tri = c->mw_tri;
+    p.smask_levels = p.smask ? c->smask_levels : 0;
     // ray binning on triangle clusters: fast build, TIGHT sets only (the bins are built from them)
     const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) && p.smask &&
                       c->math == PTGPU_MATH_FAST;
@@ -327,6 +328,7 @@ struct ShadowTables {
     std::vector<unsigned> light_ball;                // per light: sphere groups tested by the ray's end point (BALL)
     std::vector<float4> enclosing;                   // spheres ENCLOSED dropped from at least one set
     bool tables_built = false;
+    int levels = 0;                                  // of the range table appended to safe / tight / enclosed / ball
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
     double mean_safe = 0, mean_tight = 0, mean_enclosed = 0; // primitives tested per shadow ray, light-averaged
 };
@@ -602,6 +604,24 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     masks(PTGPU_CULL_ENCLOSED, t.enclosed, t.mean_enclosed);
     double mean_ball;
     masks(PTGPU_CULL_BALL, t.ball, mean_ball);
+    // Range table (device_params.h, smask_levels): a batch of shadow rays aims at a RANGE of lights and scans
+    // the union of their sets; level k holds the union over 2^k consecutive lights, so any range is the OR
+    // of two entries - two independent loads instead of a dependent load per light.  Level 0 is the table itself.
+    t.levels = 0;
+    if (words == 2 && n_lights >= 2 && n_lights <= (1u << 16)) {
+        int levels = 1;
+        while ((2u << (levels - 1)) <= n_lights) ++levels; // 2^(levels-1) <= n_lights
+        for (std::vector<unsigned long long> *m : {&t.safe, &t.tight, &t.enclosed, &t.ball}) {
+            m->resize((size_t)levels * n_lights * words, 0ull);
+            for (int k = 1; k < levels; ++k)
+                for (size_t i = 0; i + (1u << k) <= n_lights; ++i)
+                    for (int w = 0; w < words; ++w)
+                        (*m)[((size_t)k * n_lights + i) * words + w] =
+                            (*m)[((size_t)(k - 1) * n_lights + i) * words + w] |
+                            (*m)[((size_t)(k - 1) * n_lights + i + (1u << (k - 1))) * words + w];
+        }
+        t.levels = levels;
+    }
     {
         const std::vector<uint8_t> tight = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_TIGHT);
         for (size_t i = 0; i < n_prims; ++i) {
@@ -1101,6 +1121,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     ctx->sg_tri = st.sg_tri;
     ctx->mw_sph = st.mw_sph;
     ctx->mw_tri = st.mw_tri;
+    ctx->smask_levels = use_tables ? st.levels : 0;
     ctx->lds_strict = lds_strict;
     ctx->lds_strict_cull = lds_strict_cull;
     ctx->lds_fast = lds_fast;

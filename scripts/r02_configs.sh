@@ -9,7 +9,7 @@ run() { # name, bench args...
   rc=$?; echo "rc=$rc"; case $rc in 124|134|137|139) exit $rc;; esac
 }
 prof() { echo "== profile $*"; timeout -k 10 400 scripts/profile_r02.sh "$@" > /dev/null 2>&1; rc=$?; echo "rc=$rc"; case $rc in 124|134|137|139) exit $rc;; esac; }
-for cfg in "materials_pt --scene materials" "materials_dl --scene materials --integrator dl" "caustic_pt --scene caustic" \
+for cfg in "cornell_pt --scene cornell" "materials_pt --scene materials" "materials_dl --scene materials --integrator dl" "caustic_pt --scene caustic" \
            "caustic_dl --scene caustic --integrator dl" "obj-model_pt --scene obj-model" "obj-model-bunny_pt --scene obj-model-bunny" \
            "cornell-large_4k_pt --scene cornell-large --width 3840 --height 2160"; do
   set -- $cfg; name=$1; shift

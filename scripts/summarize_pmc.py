@@ -1,5 +1,5 @@
 """Sum rocprofv3 --pmc CSV rows of the dominant radiance kernel (one directory per pass) and derive the
-figures bench.py and DESIGN.md quote.  usage: summarize_pmc.py <pmc dir> <workload key> <passes per dispatch> [out.json]
+figures bench.py and DESIGN.md quote.  usage: summarize_pmc.py <pmc dir> <workload key> <render passes of the profiled run> [out.json]
 
 Derived (MI355X_MICROARCH.md, rocprofv3 PMC slots / HBM):
   active_lane_fraction    SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)   (thread-cycles per issued wave instruction)
@@ -31,7 +31,8 @@ kernel = max(tot, key=lambda k: tot[k].get("SQ_INSTS_VALU", 0) + tot[k].get("SQ_
 c = tot[kernel]
 n_disp = max(len(v) for v in disp[kernel].values())
 g = lambda n: c.get(n)
-out = {"kernel": kernel, "dispatches_per_pmc_pass": n_disp, "passes": passes * n_disp,
+# `passes` = render passes of the whole profiled run (scripts/profile_r02.sh: 2), however many dispatches they took
+out = {"kernel": kernel, "dispatches_per_pmc_pass": n_disp, "passes": passes,
        "vgpr": g("_vgpr"), "sgpr": g("_sgpr"), "lds_block_bytes": g("_lds"), "scratch_bytes_per_lane": g("_scratch"),
        "workgroup_size": g("_wg")}
 for name in sorted(c):

@@ -50,6 +50,7 @@ FLOPS = {"sphere_tests": 20,            # geomfunc.h:10-39: 3 sub, 2 dots (10), 
          "plane_side_tests": 5,         # dot of 3 against the light's plane
          "segment_near_tests": 21,      # 3 sub, dot, med3, 3 fma, dot, mul
          "ball_point_tests": 8,         # 3 sub, dot of 3
+         "convex_plane_tests": 13,      # 2 dots of 3, sub, rcp, mul (segment_crosses_convex)
          "extension_rays": 120}         # shading of a closest hit, beside its primitive tests
 # a light point sampled once more for a binned ray (wf_trace_near): sqrt, 2 scales, 2 adds, sub, dot, rsq, scale
 FLOPS_RESAMPLED_POINT = 33

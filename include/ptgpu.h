@@ -49,7 +49,13 @@ enum {
     PTGPU_OPT_SHADOW_CULL = 6,       /* PTGPU_CULL_* (default AUTO): which primitives a shadow ray
                                         towards a one-sided triangle light is tested against     */
     PTGPU_OPT_RAY_BINS = 7,          /* 1 (default) = fast build with TIGHT sets bins shadow rays on
-                                        triangle clusters (wavefront kernel); 0 = one queue        */
+                                        triangle clusters (wavefront kernel): a ray that comes near no cluster's
+                                        bounding sphere skips the clustered triangles; the others are traced in
+                                        dense batches against the clusters they come near - a cluster that is a
+                                        closed convex mesh (a box) by the planes of its faces: the segment crosses
+                                        its boundary between EPSILON and maxt exactly when the any-hit scan over its
+                                        triangles reports a hit, up to rays grazing an edge within rounding;
+                                        0 = one queue, every triangle of the sets tested                 */
     PTGPU_OPT_BVH = 8,               /* PTGPU_BVH_* (default AUTO)                                  */
     PTGPU_OPT_WORK_QUEUE = 9         /* wavefront kernel: 1 = a render call is ONE launch that fills the
                                         chip once, its waves taking units (one tile x 1..16 consecutive
@@ -277,6 +283,7 @@ enum {
     PTGPU_WORK_PATHS,
     PTGPU_WORK_NODE_LANE_SLOTS,    /* 64 per wave and node step: with BVH_NODES, the lane utilisation of the walks */
     PTGPU_WORK_PRIM_LANE_SLOTS,    /* 64 per wave and primitive test: likewise, against the three test counters   */
+    PTGPU_WORK_CONVEX_PLANE_TESTS, /* face planes of a closed convex cluster against a shadow segment, ~13 each    */
     PTGPU_WORK_SLOTS = 16
 };
 int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters /* [PTGPU_WORK_SLOTS] */, int reset);

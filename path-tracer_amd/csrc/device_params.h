@@ -106,8 +106,11 @@ struct PtDeviceParams {
     // triangle clusters (fast build, TIGHT sets): n_clusters == 0 switches the ray binning off
     const unsigned long long *cmask;  // (1 + n_clusters) x mw_tri words: row 0 = triangle groups in no
                                       // cluster, row 1 + c = groups of cluster c
-    const float4 *cbounds;            // n_clusters x (centre, padded radius), staged after the lights
-    int n_clusters;
+    const float4 *cbounds;            // cluster table, n_cquads quads staged after the lights: n_clusters x (centre, padded
+                                      // radius), then the outward face planes (unit normal, offset) of the clusters that
+                                      // are closed convex meshes, cluster by cluster
+    int n_clusters, n_cquads;
+    unsigned convex_counts;           // planes of cluster c in bits 4c..4c+3 (0 = not a closed convex mesh)
     // BVH; n_bnodes == 0 switches it off
     const float4 *bvh;
     const int *bvh_ids, *bvh_rest_ids;

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <map>
 #include <mutex>
@@ -112,7 +113,8 @@ struct ptgpu_ctx {
     int n_hnodes = 0;
     uint32_t lds_fast_hyb = 0;
     uint32_t lds_bvh = 0, lds_bvh_nodes = 0; // whole block + lights; nodes + lights (when the block does not fit)
-    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0, smask_levels = 0;
+    int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0, n_clusters = 0, n_cquads = 0, smask_levels = 0;
+    unsigned convex_counts = 0;
     // LDS for the staged records per build and cull state (0 = does not fit, read from global)
     uint32_t lds_strict = 0, lds_strict_cull = 0, lds_fast = 0;
     bool have_scene = false, have_camera = false;
@@ -285,6 +287,8 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) && p.smask &&
                       c->math == PTGPU_MATH_FAST;
     p.n_clusters = bins ? c->n_clusters : 0;
+    p.n_cquads = bins ? c->n_cquads : 0;
+    p.convex_counts = bins ? c->convex_counts : 0u;
     p.cmask = c->d_cmask;
     p.cbounds = c->d_cbounds;
     const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
@@ -296,6 +300,8 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
         p.smask = nullptr;
         p.ball_groups = 0;
         p.n_clusters = 0;
+        p.n_cquads = 0;
+        p.convex_counts = 0;
         p.bvh = c->d_bvh;
         const bool strict = c->math == PTGPU_MATH_STRICT;
         p.bvh_ids = strict ? c->d_bvh_ids_index : c->d_bvh_ids_slot;
@@ -321,6 +327,8 @@ struct ShadowTables {
     std::vector<int> prim_of_slot;   // shadow-order slot -> primitive index, -1 for a filler
     std::vector<int> cluster_of;     // primitive -> triangle cluster or -1
     std::vector<float4> cluster_bounds;              // (centre, padded radius) per cluster
+    std::vector<float4> cluster_table;               // the bounds, then per cluster its convex planes (if any)
+    unsigned convex_counts = 0;                      // planes per cluster, a nibble each
     std::vector<unsigned long long> cluster_masks;   // (1 + clusters) x mw_tri words
     std::vector<unsigned> light_clusters;            // per light: clusters present in its TIGHT set
     std::vector<float4> hyb_nodes;                   // hierarchy whose leaves are the triangle groups
@@ -490,10 +498,85 @@ std::vector<int> find_clusters(const std::vector<float4> &prims, const std::vect
     return cluster_of;
 }
 
+// A cluster that is a CLOSED CONVEX mesh (cornell.txt's cube) need not be tested triangle by triangle by a shadow
+// ray: the ray is occluded by it exactly when the segment crosses its boundary between EPSILON and maxt, which the
+// planes of its faces decide (device: segment_crosses_convex).  Returns the outward planes (unit normal, offset;
+// coplanar faces merged) or nothing when the cluster is not such a mesh or has more than kMaxConvexPlanes faces.
+constexpr int kMaxConvexPlanes = 15; // a nibble per cluster (8 clusters: one 32-bit kernel argument)
+std::vector<float4> convex_planes(const std::vector<float4> &prims, const std::vector<int> &cluster_of, int cluster) {
+    std::vector<D3> verts;
+    std::vector<std::array<D3, 3>> tris;
+    for (size_t i = 0; i < cluster_of.size(); ++i) {
+        if (cluster_of[i] != cluster) continue;
+        const D3 a = d3(prims[3 * i]), b = add(a, d3(prims[3 * i + 1])), c = add(a, d3(prims[3 * i + 2]));
+        tris.push_back({a, b, c});
+        verts.push_back(a); verts.push_back(b); verts.push_back(c);
+    }
+    if (tris.size() < 4) return {};
+    D3 mid{0, 0, 0};
+    double scale = 0;
+    for (const D3 &v : verts) mid = add(mid, v);
+    mid = {mid.x / verts.size(), mid.y / verts.size(), mid.z / verts.size()};
+    for (const D3 &v : verts) scale = std::max(scale, len(sub(v, mid)));
+    if (!(scale > 0) || !std::isfinite(scale)) return {};
+    const double tol = 1e-5 * scale;
+    // closed: every edge (by quantised end points) is used by exactly two triangles
+    auto key = [&](const D3 &v) {
+        return std::array<long long, 3>{llround((v.x - mid.x) / tol / 4), llround((v.y - mid.y) / tol / 4), llround((v.z - mid.z) / tol / 4)};
+    };
+    std::map<std::pair<std::array<long long, 3>, std::array<long long, 3>>, int> edges;
+    for (const auto &t : tris)
+        for (int e = 0; e < 3; ++e) {
+            auto a = key(t[e]), b = key(t[(e + 1) % 3]);
+            if (a == b) return {}; // degenerate triangle
+            if (b < a) std::swap(a, b);
+            edges[{a, b}]++;
+        }
+    for (const auto &kv : edges)
+        if (kv.second != 2) return {};
+    // convex: every vertex on or behind every face's plane, the plane oriented away from the centroid
+    std::vector<float4> planes;
+    std::vector<D3> normals;
+    std::vector<double> offsets;
+    for (const auto &t : tris) {
+        D3 n = cross(sub(t[1], t[0]), sub(t[2], t[0]));
+        const double nn = len(n);
+        if (!(nn > 1e-12 * scale * scale)) return {};
+        n = {n.x / nn, n.y / nn, n.z / nn};
+        double w = dot(n, t[0]);
+        if (dot(n, mid) > w) { n = {-n.x, -n.y, -n.z}; w = -w; }
+        for (const D3 &v : verts)
+            if (dot(n, v) > w + tol) return {};
+        bool seen = false;
+        for (size_t k = 0; k < normals.size() && !seen; ++k)
+            seen = len(sub(normals[k], n)) < 1e-6 && std::fabs(offsets[k] - w) < tol;
+        if (seen) continue;
+        normals.push_back(n);
+        offsets.push_back(w);
+        planes.push_back(make_float4((float)n.x, (float)n.y, (float)n.z, (float)w));
+        if ((int)planes.size() > kMaxConvexPlanes) return {};
+    }
+    return planes;
+}
+
 void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int> &types,
                          const std::vector<float4> &lights, const std::vector<uint8_t> &dielectric, ShadowTables &t) {
     t.cluster_of = find_clusters(prims, types, t.cluster_bounds);
     const int n_clusters = (int)t.cluster_bounds.size();
+    // cluster table (device_params.h, cbounds): [bounds][planes of the convex clusters, cluster by cluster]; the plane
+    // counts travel as a kernel argument, a nibble per cluster (LDS is short: cornell.txt's workgroup fits three to
+    // a CU with 112 bytes to spare - its six cube planes are 96)
+    {
+        std::vector<float4> planes;
+        t.convex_counts = 0;
+        for (int c = 0; c < n_clusters; ++c) {
+            const std::vector<float4> pc = convex_planes(prims, t.cluster_of, c);
+            t.convex_counts |= (unsigned)pc.size() << (4 * c);
+            planes.insert(planes.end(), pc.begin(), pc.end());
+        }
+        t.cluster_table = t.cluster_bounds;
+        t.cluster_table.insert(t.cluster_table.end(), planes.begin(), planes.end());
+    }
     // shadow order: spheres; then the triangles of cluster 0, 1, ... each padded to whole groups;
     // then the unclustered triangles.  slots[] = primitive index or -1 for a never-hit filler.
     std::vector<int> sph_slots, tri_slots;
@@ -1013,7 +1096,10 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     // and stay small.
     ShadowTables st;
     build_shadow_tables(prims, types, lights, geo.dielectric, st);
-    if (info.lights >= (1u << 18)) st.cluster_bounds.clear(); // the near-queue tag holds 18 bits of light index
+    if (info.lights >= (1u << 18)) { // the near-queue tag holds 18 bits of light index
+        st.cluster_bounds.clear();
+        st.cluster_table.clear();
+    }
     for (size_t l = 0; l < st.light_clusters.size(); ++l)   // l1.w is free in both light kinds
         dlights[kLightQuads * l + 1].w = as_float(st.cluster_bounds.empty() ? 0 : (int)st.light_clusters[l]);
     unsigned ball_groups = 0;
@@ -1033,8 +1119,8 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     const size_t light_bytes = dlights.size() * sizeof(float4), shadow_bytes = st.sprims.size() * sizeof(float4);
     const uint32_t lds_strict = fits(prims.size() * sizeof(float4) + light_bytes);
     const uint32_t lds_strict_cull = fits(prims.size() * sizeof(float4) + light_bytes + shadow_bytes);
-    const uint32_t lds_fast = fits(shadow_bytes + light_bytes + st.cluster_bounds.size() * sizeof(float4));
-    const uint32_t lds_fast_hyb = fits(shadow_bytes + light_bytes + (st.cluster_bounds.size() + st.hyb_nodes.size()) * sizeof(float4));
+    const uint32_t lds_fast = fits(shadow_bytes + light_bytes + st.cluster_table.size() * sizeof(float4));
+    const uint32_t lds_fast_hyb = fits(shadow_bytes + light_bytes + (st.cluster_table.size() + st.hyb_nodes.size()) * sizeof(float4));
     info.lds_bytes = lds_fast;
 
     // BVH: built for every scene with something to gain; AUTO uses it when the candidate sets do
@@ -1093,7 +1179,9 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         HIP_TRY(upload(ctx->d_smask_ball, st.ball));
         ctx->enclosing = st.enclosing;
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
-        HIP_TRY(upload(ctx->d_cbounds, st.cluster_bounds));
+        HIP_TRY(upload(ctx->d_cbounds, st.cluster_table));
+        ctx->n_cquads = (int)st.cluster_table.size();
+        ctx->convex_counts = st.convex_counts;
     }
     if (!bvh.nodes.empty()) {
         HIP_TRY(upload(ctx->d_bvh, bvh_block));
@@ -1115,6 +1203,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     ctx->lds_bvh = lds_bvh;
     ctx->lds_bvh_nodes = lds_bvh_nodes;
     ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
+    if (!use_tables) ctx->n_cquads = 0;
     info.clusters = (uint32_t)ctx->n_clusters;
     for (int c : st.cluster_of) info.clustered_triangles += (ctx->n_clusters && c >= 0) ? 1u : 0u;
     ctx->sg_sph = st.sg_sph;

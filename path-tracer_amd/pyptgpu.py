@@ -255,7 +255,7 @@ class LaunchInfo(C.Structure):
 INSTANCE_NAMES = {0: "plain", 1: "bvh", 2: "hybrid", 3: "ball"}
 WORK_SLOTS = ("sphere_tests", "triangle_tests_mt", "triangle_tests_planes", "bvh_nodes", "light_samples",
               "light_points", "plane_side_tests", "segment_near_tests", "ball_point_tests", "extension_rays",
-              "shadow_rays", "rng_draws", "paths", "node_lane_slots", "prim_lane_slots")
+              "shadow_rays", "rng_draws", "paths", "node_lane_slots", "prim_lane_slots", "convex_plane_tests")
 
 
 class GpuError(RuntimeError):

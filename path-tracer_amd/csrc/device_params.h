@@ -116,6 +116,8 @@ struct PtDeviceParams {
     const int *bvh_ids, *bvh_rest_ids;
     int n_bnodes, n_bslots, n_brest, bvh_type;
     int bvh_nodes_only;   // 1: only the nodes (and the lights) are staged in LDS, leaves are read from global memory
+    int coop_stragglers;  // cooperative walks (radiance_kernels.inc): the lanes still walking towards a leaf stop for
+                          // now once fewer than this many are left, and what they have left is shared out (0: never)
     // hybrid (fast build with candidate sets): a hierarchy whose leaves are the triangle groups of
     // sprims (leaf `first` = slot within the triangle section); n_hnodes == 0 switches it off
     const float4 *hyb_nodes;

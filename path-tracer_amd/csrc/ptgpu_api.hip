@@ -78,6 +78,9 @@ bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 
 
 } // namespace
 
+#ifndef PT_COOP_STRAGGLERS
+#define PT_COOP_STRAGGLERS 24 // measured 16 .. 48 on obj-model.txt, its bunny variant and large-object.txt
+#endif
 struct ptgpu_ctx {
     int device = 0;
     int integrator = PT_INTEGRATOR_PT;
@@ -307,6 +310,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
         p.bvh_ids = strict ? c->d_bvh_ids_index : c->d_bvh_ids_slot;
         p.bvh_rest_ids = strict ? c->d_bvh_rest_index : c->d_bvh_rest_slot;
         p.n_bnodes = c->n_bnodes;
+        p.coop_stragglers = PT_COOP_STRAGGLERS;
         p.n_bslots = c->n_bslots;
         p.n_brest = c->n_brest;
         p.bvh_type = c->bvh_type;
@@ -775,14 +779,18 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
 
     // AUTO: the shadow-ray queues pay with two or more lights and incoherent hit points; the direct
     // lighting integrator stops at the (tile-coherent) first hit, where the inline loop is ahead.
-    // A large triangle hierarchy is the other case for the wavefront kernel (its shadow rays walk
-    // the tree in dense batches): large-object 614 -> 940, the bunny scene 161 -> 184 Mpaths/s; a
-    // sphere hierarchy or a small mesh is not (complex 2 235 -> 2 081, table-and-mirror 1 772 -> 1 509).
-    const bool big_mesh = probe.n_bnodes > 0 && probe.bvh_type == PT_TRIANGLE && probe.n_bslots >= 512;
+    // A hierarchy is the other case for the wavefront kernel: its rays' walks are shared out over the wave
+    // (radiance_kernels.inc, coop_walk) - mega / wavefront Mpaths/s: large-object 617 / 1 766, obj-model 1 156 /
+    // 1 629, the bunny scene 162 / 519, table-and-mirror 1 740 / 2 547, complex (a sphere hierarchy) 2 161 / 2 403
+    // (scripts/kernel_choice.py).
+    // With the direct-lighting integrator only a large triangle mesh is (mega / wavefront: the bunny scene 813 /
+    // 1 973, large-object 6 981 / 8 483, but obj-model 8 321 / 8 117, table-and-mirror 10 339 / 8 756).
+    const bool hierarchy = probe.n_bnodes > 0;
+    const bool big_mesh = hierarchy && probe.bvh_type == PT_TRIANGLE && probe.n_bslots >= 512;
     const int kernel = img.is_static                  ? PTGPU_KERNEL_WAVEFRONT
                        : c->kernel != PTGPU_KERNEL_AUTO ? c->kernel
-                       : ((c->info.lights >= 2 || big_mesh) && c->integrator == PT_INTEGRATOR_PT ? PTGPU_KERNEL_WAVEFRONT
-                                                                                                 : PTGPU_KERNEL_MEGA);
+                       : c->integrator == PT_INTEGRATOR_PT ? (c->info.lights >= 2 || hierarchy ? PTGPU_KERNEL_WAVEFRONT : PTGPU_KERNEL_MEGA)
+                                                           : (big_mesh ? PTGPU_KERNEL_WAVEFRONT : PTGPU_KERNEL_MEGA);
     // a hierarchy too large for LDS is staged nodes only, where that pays: the wavefront kernel
     // (one large workgroup per CU shares the nodes; the mega kernel's 4-wave groups would each
     // hold a copy)

@@ -98,6 +98,10 @@ def test_bvh_full_size_equals_linear_scan(name, lds):
     off = gpu_render(name, w, h, spp, 0, pt.KERNEL_MEGA, pt.MATH_STRICT, lds=lds, bvh=pt.BVH_OFF, cull=pt.CULL_OFF)
     on = gpu_render(name, w, h, spp, 0, pt.KERNEL_MEGA, pt.MATH_STRICT, lds=lds, bvh=pt.BVH_ON)
     assert same_bits(off[0], on[0]) and (off[1] == on[1]).all() and (off[2] == on[2]).all()
+    # the wavefront kernel shares the walks of a wave's rays out over its lanes (ranges of the node array handed
+    # from lane to lane, a ray's closest hit a 64-bit minimum in LDS): whatever the order, the same hit
+    coop = gpu_render(name, w, h, spp, 0, pt.KERNEL_WAVEFRONT, pt.MATH_STRICT, lds=lds, bvh=pt.BVH_ON)
+    assert same_bits(off[0], coop[0]) and (off[1] == coop[1]).all() and (off[2] == coop[2]).all()
 
 
 def test_bvh_nodes_only_staging_equals_the_other_paths():

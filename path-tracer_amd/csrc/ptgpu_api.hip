@@ -108,7 +108,7 @@ struct ptgpu_ctx {
     std::vector<float4> enclosing; // (centre, radius) of the spheres PTGPU_CULL_ENCLOSED took out of a set
     float4 *d_cbounds = nullptr;
     // BVH (device_params.h): one block + the id tables in each build's numbering
-    float4 *d_bvh = nullptr;
+    float4 *d_bvh = nullptr, *d_bvh_planes = nullptr; // (the fast build's copy: leaf triangles in plane form)
     int *d_bvh_ids_index = nullptr, *d_bvh_ids_slot = nullptr, *d_bvh_rest_index = nullptr, *d_bvh_rest_slot = nullptr;
     int n_bnodes = 0, n_bslots = 0, n_brest = 0, bvh_type = 0;
     bool bvh_auto = false;             // AUTO turns it on for this scene
@@ -162,11 +162,12 @@ void free_scene(ptgpu_ctx *c) {
     c->d_cmask = nullptr;
     c->d_cbounds = nullptr;
     if (c->d_bvh) (void)hipFree(c->d_bvh);
+    if (c->d_bvh_planes) (void)hipFree(c->d_bvh_planes);
     for (int **q : {&c->d_bvh_ids_index, &c->d_bvh_ids_slot, &c->d_bvh_rest_index, &c->d_bvh_rest_slot}) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
-    c->d_bvh = nullptr;
+    c->d_bvh = c->d_bvh_planes = nullptr;
     c->n_bnodes = c->n_bslots = c->n_brest = 0;
     if (c->d_hyb_nodes) (void)hipFree(c->d_hyb_nodes);
     c->d_hyb_nodes = nullptr;
@@ -297,7 +298,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
     // the fast build's own translation units read triangles in plane form (radiance_device.inc)
 #if !(defined(PT_EXACT) && (PT_EXACT & 16)) // (measurement build with Moeller-Trumbore in the fast kernels: scripts/bias_bisect.sh)
-    if (c->math == PTGPU_MATH_FAST && !use_bvh) p.sprims = c->d_sprims_planes;
+    if (c->math == PTGPU_MATH_FAST) p.sprims = c->d_sprims_planes;
 #endif
     if (use_bvh) { // the hierarchy replaces the candidate sets
         p.smask = nullptr;
@@ -306,6 +307,9 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
         p.n_cquads = 0;
         p.convex_counts = 0;
         p.bvh = c->d_bvh;
+#if !(defined(PT_EXACT) && (PT_EXACT & 16))
+        if (c->math == PTGPU_MATH_FAST) p.bvh = c->d_bvh_planes;
+#endif
         const bool strict = c->math == PTGPU_MATH_STRICT;
         p.bvh_ids = strict ? c->d_bvh_ids_index : c->d_bvh_ids_slot;
         p.bvh_rest_ids = strict ? c->d_bvh_rest_index : c->d_bvh_rest_slot;
@@ -352,6 +356,20 @@ D3 add(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 D3 cross(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 double len(D3 a) { return std::sqrt(dot(a, a)); }
+
+// (p1, e1, e2) -> the plane form of a triangle record (radiance_device.inc, triangle_planes_t), in place
+void to_plane_form(float4 *q) {
+    const D3 p1 = d3(q[0]), e1 = d3(q[1]), e2 = d3(q[2]);
+    const D3 n = cross(e1, e2);
+    const double nn = dot(n, n);
+    q[0] = q[1] = q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(nn > 0.0) || !std::isfinite(nn) || !std::isfinite(dot(p1, p1))) return;
+    const D3 c1 = cross(e2, n), c2 = cross(n, e1);
+    const D3 n1 = {c1.x / nn, c1.y / nn, c1.z / nn}, n2 = {c2.x / nn, c2.y / nn, c2.z / nn};
+    q[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)dot(n, p1));
+    q[1] = make_float4((float)n1.x, (float)n1.y, (float)n1.z, (float)-dot(n1, p1));
+    q[2] = make_float4((float)n2.x, (float)n2.y, (float)n2.z, (float)-dot(n2, p1));
+}
 
 // keep[l * n_prims + i] = primitive i may occlude a shadow ray towards light l under `mode`
 // (PTGPU_CULL_SAFE / TIGHT / ENCLOSED / BALL, ptgpu.h; anything else keeps everything); under BALL
@@ -636,19 +654,7 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     // plane form of the triangles (radiance_device.inc, triangle_planes_t), derived in double; a
     // triangle without area or with a non-finite coordinate becomes the never-hit filler
     t.sprims_planes = t.sprims;
-    for (size_t slot = sph_slots.size(); slot < t.prim_of_slot.size(); ++slot) {
-        float4 *q = &t.sprims_planes[3 * slot];
-        const D3 p1 = d3(q[0]), e1 = d3(q[1]), e2 = d3(q[2]);
-        const D3 n = cross(e1, e2);
-        const double nn = dot(n, n);
-        q[0] = q[1] = q[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(nn > 0.0) || !std::isfinite(nn) || !std::isfinite(dot(p1, p1))) continue;
-        const D3 c1 = cross(e2, n), c2 = cross(n, e1);
-        const D3 n1 = {c1.x / nn, c1.y / nn, c1.z / nn}, n2 = {c2.x / nn, c2.y / nn, c2.z / nn};
-        q[0] = make_float4((float)n.x, (float)n.y, (float)n.z, (float)dot(n, p1));
-        q[1] = make_float4((float)n1.x, (float)n1.y, (float)n1.z, (float)-dot(n1, p1));
-        q[2] = make_float4((float)n2.x, (float)n2.y, (float)n2.z, (float)-dot(n2, p1));
-    }
+    for (size_t slot = sph_slots.size(); slot < t.prim_of_slot.size(); ++slot) to_plane_form(&t.sprims_planes[3 * slot]);
 
     // cluster_masks: row 0 = triangle groups outside every cluster, row 1 + c = groups of cluster c
     t.cluster_masks.assign((size_t)(n_clusters + 1) * t.mw_tri, 0ull);
@@ -1193,6 +1199,11 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     }
     if (!bvh.nodes.empty()) {
         HIP_TRY(upload(ctx->d_bvh, bvh_block));
+        // the fast build reads the triangles of the leaves in plane form, as it does everywhere else (the few
+        // primitives outside the hierarchy keep their records: rest_prim_t)
+        if (bvh.type == PT_TRIANGLE)
+            for (size_t slot = 0; slot < bvh.prim_of_slot.size(); ++slot) to_plane_form(&bvh_block[bvh.nodes.size() + 3 * slot]);
+        HIP_TRY(upload(ctx->d_bvh_planes, bvh_block));
         HIP_TRY(upload(ctx->d_bvh_ids_index, ids_index));
         HIP_TRY(upload(ctx->d_bvh_ids_slot, ids_slot));
         HIP_TRY(upload(ctx->d_bvh_rest_index, rest_index));

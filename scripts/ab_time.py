@@ -1,14 +1,17 @@
 """A/B timing on one GPU box: each library named on the command line (default: the base build and the working
 tree's) renders the same cases, interleaved over several rounds; prints the best ms per pass of each.
-usage: ab_time.py [--cases cornell,materials,...] [lib.so ...]"""
+usage: ab_time.py [--cases cornell,materials,...] [--cull ball] [lib.so ...]"""
 import sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import pyptgpu as pt
 args = sys.argv[1:]
 cases = ["cornell"]
-if args and args[0] == "--cases":
-    cases = args[1].split(","); args = args[2:]
+kw = {}
+while args and args[0] in ("--cases", "--cull"):
+    if args[0] == "--cases": cases = args[1].split(",")
+    else: kw["shadow_cull"] = {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED, "ball": pt.CULL_BALL}[args[1]]
+    args = args[2:]
 libs = args or [pt.variant_path("base"), os.path.join(REPO, "path-tracer_amd", "libptgpu.so")]
 W, H = 1024, 768
 for scn in cases:
@@ -16,7 +19,7 @@ for scn in cases:
     sc = pt.LoadedScene(name, W, H); seeds = pt.seed_block(W, H)
     gs = []
     for lib in libs:
-        g = pt.Gpu(0, 1 if integ == "dl" else 0, lib=lib); g.set_scene(sc); g.resize(W, H, seeds)
+        g = pt.Gpu(0, 1 if integ == "dl" else 0, lib=lib, **kw); g.set_scene(sc); g.resize(W, H, seeds)
         info = g.scene_info()
         n = 32 if info["primitives"] * (1 + info["lights"]) > 2000 else 128
         g.render_timed(n)

@@ -240,6 +240,8 @@ typedef struct ptgpu_scene_info {
     uint32_t clustered_triangles;  /* triangles inside them */
     uint32_t bvh_nodes;            /* nodes of the hierarchy built for PTGPU_OPT_BVH (0 = none) */
     uint32_t bvh_primitives;       /* primitives inside it; the others are scanned one by one */
+    uint32_t convex_clusters;      /* clusters that are closed convex meshes of <= 15 planes: near shadow rays test
+                                      their face planes instead of their triangles (PTGPU_OPT_RAY_BINS) */
 } ptgpu_scene_info;
 int ptgpu_get_scene_info(ptgpu_ctx *ctx, ptgpu_scene_info *info);
 

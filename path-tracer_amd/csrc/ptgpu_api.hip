@@ -1224,6 +1224,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     ctx->n_clusters = use_tables ? (int)st.cluster_bounds.size() : 0;
     if (!use_tables) ctx->n_cquads = 0;
     info.clusters = (uint32_t)ctx->n_clusters;
+    for (int c = 0; c < ctx->n_clusters; ++c) info.convex_clusters += ((ctx->convex_counts >> (4 * c)) & 15u) ? 1u : 0u;
     for (int c : st.cluster_of) info.clustered_triangles += (ctx->n_clusters && c >= 0) ? 1u : 0u;
     ctx->sg_sph = st.sg_sph;
     ctx->sg_tri = st.sg_tri;

@@ -235,7 +235,7 @@ class SceneInfo(C.Structure):
                                           "lds_bytes", "shadow_groups")]
                 + [("shadow_tests_safe", C.c_float), ("shadow_tests_tight", C.c_float),
                    ("shadow_tests_enclosed", C.c_float), ("clusters", C.c_uint32), ("clustered_triangles", C.c_uint32),
-                   ("bvh_nodes", C.c_uint32), ("bvh_primitives", C.c_uint32)])
+                   ("bvh_nodes", C.c_uint32), ("bvh_primitives", C.c_uint32), ("convex_clusters", C.c_uint32)])
 
 
 GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_scene", "ptgpu_set_camera",

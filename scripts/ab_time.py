@@ -8,8 +8,10 @@ import pyptgpu as pt
 args = sys.argv[1:]
 cases = ["cornell"]
 kw = {}
-while args and args[0] in ("--cases", "--cull"):
+waves = None
+while args and args[0] in ("--cases", "--cull", "--waves"):
     if args[0] == "--cases": cases = args[1].split(",")
+    elif args[0] == "--waves": waves = [int(x) for x in args[1].split(",")]   # waves per group, one per library
     else: kw["shadow_cull"] = {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED, "ball": pt.CULL_BALL}[args[1]]
     args = args[2:]
 libs = args or [pt.variant_path("base"), os.path.join(REPO, "path-tracer_amd", "libptgpu.so")]
@@ -18,7 +20,8 @@ for scn in cases:
     name, _, integ = scn.partition(":")
     sc = pt.LoadedScene(name, W, H); seeds = pt.seed_block(W, H)
     gs = []
-    for lib in libs:
+    for li, lib in enumerate(libs):
+        if waves: kw["waves_per_group"] = waves[li] or None
         g = pt.Gpu(0, 1 if integ == "dl" else 0, lib=lib, **kw); g.set_scene(sc); g.resize(W, H, seeds)
         info = g.scene_info()
         n = 32 if info["primitives"] * (1 + info["lights"]) > 2000 else 128

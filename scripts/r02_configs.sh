@@ -1,6 +1,10 @@
 #!/bin/bash
 # BASELINE configs 3, 4, 5 (+ cornell with the other candidate-set modes): one bench line and one rocprofv3
 # evidence set each (run on the GPU box via gpurun).  Results under gpurun_out/bench_r02 and gpurun_out/prof_r02.
+#   scripts/r02_configs.sh prof    the rocprofv3 evidence (kernel stats + PMC passes) of every config
+#   scripts/r02_configs.sh bench   the bench lines - AFTER `python scripts/collect_r02.py` has put the PMC summaries
+#                                  of the prof phase under profiles/r02/: a line's issued-FP32 figure is built from them
+PHASE=${1:-both}
 mkdir -p gpurun_out/bench_r02
 run() { # name, bench args...
   local name=$1; shift
@@ -13,9 +17,10 @@ for cfg in "cornell_pt --scene cornell" "materials_pt --scene materials" "materi
            "caustic_dl --scene caustic --integrator dl" "obj-model_pt --scene obj-model" "obj-model-bunny_pt --scene obj-model-bunny" \
            "cornell-large_4k_pt --scene cornell-large --width 3840 --height 2160"; do
   set -- $cfg; name=$1; shift
-  run $name "$@"
-  prof "$@"
+  [ $PHASE != prof ] && run $name "$@"
+  [ $PHASE != bench ] && prof "$@"
 done
+[ $PHASE = prof ] && exit 0
 run cornell_cull_safe --cull safe --no-cpu
 run cornell_cull_tight --cull tight --no-cpu
 run cornell_cull_ball --cull ball --no-cpu

@@ -161,6 +161,16 @@ def committed_profile(workload_key):
         return None
 
 
+def keep_stdout_for_the_line():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner to the process's stdout when its
+    first communicator comes up (and other libraries may print as they load): from here on file descriptor 1 is
+    stderr, and the line goes to the descriptor returned, the stdout this process was started with."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +230,7 @@ def main():
 
     # The library's region streams are created BEFORE the process group: HIP spreads streams over
     # GPU_MAX_HW_QUEUES (4) hardware queues in creation order.
+    out = keep_stdout_for_the_line()
     g = make_gpu()
     g.set_scene(sc)
     g.resize(w, h, seeds)
@@ -245,7 +256,7 @@ def main():
         li = g.launch_info()
         names = {v: k for k, v in culls.items() if k != "auto"}
         print(f"{args.scene}-{w}x{h}-{args.integrator}-{args.math}-{names[li['shadow_cull']]}-"
-              f"{'wavefront' if li['kernel'] == pt.KERNEL_WAVEFRONT else 'mega'}")
+              f"{'wavefront' if li['kernel'] == pt.KERNEL_WAVEFRONT else 'mega'}", file=out, flush=True)
         g.close()
         return
     for _ in range(args.warmup):
@@ -359,7 +370,7 @@ def main():
             "reference_counters_sample": ref_counters,
             "nan_pixels": int((pixels == 0x80000000).sum()),
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out, flush=True)
     g.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -313,7 +313,7 @@ def main():
         if world == 1 and not args.no_cpu:
             baseline, ref_flops_per_path, ref_counters = cpu_baseline(args.scene)
         roofline = None
-        if world == 1 and not args.no_count:
+        if not args.no_count:   # (per launch on one GPU: rank 0's kernel stands for every rank's at N > 1)
             flops_per_path, per_path, count_sample, count_li = executed_work(pt, args, make_gpu, w, h)
             achieved = flops_per_path * paths_per_step / (avg_step_ms * 1e-3) / 1e12
             prof = committed_profile(workload_key)

@@ -112,6 +112,7 @@ struct ptgpu_ctx {
     int *d_bvh_ids_index = nullptr, *d_bvh_ids_slot = nullptr, *d_bvh_rest_index = nullptr, *d_bvh_rest_slot = nullptr;
     int n_bnodes = 0, n_bslots = 0, n_brest = 0, bvh_type = 0;
     bool bvh_auto = false;             // AUTO turns it on for this scene
+    bool bvh_auto_exact = false; // a hierarchy worth walking exists, candidate sets or not
     float4 *d_hyb_nodes = nullptr;     // hierarchy over the shadow order (hybrid)
     int n_hnodes = 0;
     uint32_t lds_fast_hyb = 0;
@@ -295,7 +296,13 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.convex_counts = bins ? c->convex_counts : 0u;
     p.cmask = c->d_cmask;
     p.cbounds = c->d_cbounds;
-    const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && c->bvh_auto));
+    // AUTO: the hierarchy where the candidate sets do not apply - and, for the strict build left to its defaults
+    // under path tracing, wherever a hierarchy of some size exists: SAFE sets (what that build would scan otherwise)
+    // cull little, and any answer through the hierarchy is the linear scan's bit for bit (cornell.txt strict:
+    // 34 -> 65 Mpaths/s, scripts/strict_choice.py).  A caller who names a cull mode gets that mode's sets.
+    const bool exact_by_tree = c->math == PTGPU_MATH_STRICT && c->shadow_cull == PTGPU_CULL_AUTO &&
+                               c->integrator == PT_INTEGRATOR_PT && c->bvh_auto_exact;
+    const bool use_bvh = c->n_bnodes > 0 && (c->bvh == PTGPU_BVH_ON || (c->bvh == PTGPU_BVH_AUTO && (c->bvh_auto || exact_by_tree)));
     // the fast build's own translation units read triangles in plane form (radiance_device.inc)
 #if !(defined(PT_EXACT) && (PT_EXACT & 16)) // (measurement build with Moeller-Trumbore in the fast kernels: scripts/bias_bisect.sh)
     if (c->math == PTGPU_MATH_FAST) p.sprims = c->d_sprims_planes;
@@ -1214,6 +1221,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         ctx->bvh_type = bvh.type;
     }
     ctx->bvh_auto = !use_tables && in_tree >= 64 && bvh.rest.size() <= 64;
+    ctx->bvh_auto_exact = in_tree >= 64 && bvh.rest.size() <= 64;
     if (use_tables && st.hyb_nodes.size() / 2 >= 8 && info.triangles >= 32) {
         HIP_TRY(upload(ctx->d_hyb_nodes, st.hyb_nodes));
         ctx->n_hnodes = (int)(st.hyb_nodes.size() / 2);

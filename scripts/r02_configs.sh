@@ -25,3 +25,4 @@ run cornell_cull_safe --cull safe --no-cpu
 run cornell_cull_tight --cull tight --no-cpu
 run cornell_cull_ball --cull ball --no-cpu
 run cornell_strict --math strict --no-cpu --steps 4 --passes 16
+run cornell_strict_safe --math strict --cull safe --no-cpu --steps 4 --passes 16

@@ -22,7 +22,8 @@ print()
 print("| build | sets | Mpaths/s | executed kflop/path | frac | mean bias vs strict |")
 print("|---|---|---|---|---|---|")
 for name, label in (("cornell_pt", "fast | ENCLOSED (default)"), ("cornell_cull_ball", "fast | BALL (opt-in)"), ("cornell_cull_tight", "fast | TIGHT"),
-                    ("cornell_cull_safe", "fast | SAFE = the reference's algorithm, fast arithmetic"), ("cornell_strict", "strict | SAFE = the reference bit for bit")):
+                    ("cornell_cull_safe", "fast | SAFE = the reference's algorithm, fast arithmetic"), ("cornell_strict_safe", "strict | SAFE = the reference bit for bit, its own scan order"),
+                    ("cornell_strict", "strict | none: every ray through the hierarchy (strict default) = the reference bit for bit")):
     d = line(name); r = d["roofline"]; e = d.get("image_error") or {}
     b = e.get("mean_rel_bias")
     print(f"| {label} | {d['value']:.0f} | {r['algorithmic_flops_per_path'] / 1e3:.1f} | {r['frac']:.3f} | {'0' if b is None else f'{b:+.1e}'} |")

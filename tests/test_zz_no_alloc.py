@@ -58,7 +58,8 @@ def static_render(g, w, h, seeds, first, n):
 def test_render_static_equals_render_twice_in_a_row_second_frame_smaller(math):
     g = pt.Gpu(0, pt.INTEGRATOR_PT, math=math)   # options left at AUTO: the entry point picks its kernel itself
     try:
-        for scene, w, h, first, n in (("cornell", 200, 136, 2, 3), ("cornell", 72, 40, 0, 4), ("materials", 37, 29, 1, 2)):
+        for scene, w, h, first, n in (("cornell", 200, 136, 2, 3), ("cornell", 72, 40, 0, 4), ("materials", 37, 29, 1, 2),
+                                          ("obj-model", 96, 64, 1, 2)):   # (a hierarchy scene: cooperative walks)
             sc = pt.LoadedScene(scene, w, h)
             seeds = pt.seed_block(w, h)
             g.set_scene(sc)

@@ -51,6 +51,10 @@
 // for LDS whose nodes alone fit (a mesh of ~1 500 to ~5 600 triangles: 16 B of nodes per triangle
 // against 48 B of records) is staged nodes only, for the wavefront kernel: the walk - most of the
 // accesses - stays in LDS and each lane reads the few leaves it reaches from global memory.
+// The fast build's copy of the block holds the leaf triangles in plane form (the strict build's, and
+// the primitives outside the hierarchy in both, keep p1 / e1 / e2).  The depth-first order with skip
+// links is also what lets the wavefront kernel cut a walk anywhere: what is left of a walk is an index
+// range of the node array (radiance_kernels.inc, coop_walk).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -290,6 +290,18 @@ enum {
 };
 int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters /* [PTGPU_WORK_SLOTS] */, int reset);
 
+/* Test aid without a reference counterpart (the reference traces rays only from inside its path loop): the closest
+ * hit and the occlusion answer of rays the caller names, through the intersection routines of the build and code
+ * instance the context's options select - the place where the tie rule (geomfunc.h:149) and the hierarchy walks can be
+ * checked ray by ray (tests/test_gpu_rays.py).  origins / directions: 3 floats per ray (directions as the path
+ * loop would pass them: normalised); maxt: 1 float per ray; t: distance of the closest hit or -1; rgb: colour +
+ * emission of the surface hit; occluded: 1 if anything is hit between EPSILON and maxt.  cooperative != 0: where a
+ * hierarchy is walked, through the wavefront kernel's wave-cooperative walks.  Needs a scene and a frame
+ * (ptgpu_resize).  Only in the ray-probe build of the library (-DPT_RAY_PROBE=1, path-tracer_amd/variants/
+ * libptgpu_probe.so); elsewhere it returns PTGPU_ERR_STATE. */
+int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *directions, const float *maxt,
+                     float *t, float *rgb, int *occluded, int cooperative);
+
 /* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
  * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
  * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT, ENCLOSED or BALL (OFF:

@@ -135,16 +135,27 @@ struct PtLaunchConfig {
     int compute_units;    // of the device (work-queue launches fill the chip once, no more)
 };
 
+
+// -DPT_RAY_PROBE=1 builds only (tests/test_gpu_rays.py): the closest hit and the occlusion answer of given rays
+struct PtRayProbe {
+    int n;
+    const float *origin, *direction, *maxt; // 3, 3, 1 floats per ray
+    float *t, *rgb;                         // distance of the closest hit (-1: none), colour + emission of its surface
+    int *occluded;                          // any hit before maxt
+    int cooperative;                        // hierarchy instances: through the wavefront kernel's cooperative walks
+};
 namespace ptk_fast {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
 namespace ptk_strict {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 int launch_repack(const PtDeviceParams &p, float scale, hipStream_t s);
 }
 // the same kernels compiled with the BVH traversal in place of the linear scans (PT_BVH 1)
@@ -152,25 +163,30 @@ namespace ptk_fast_bvh {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 }
 namespace ptk_fast_hyb {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only // PT_BVH 2: extension rays through the hierarchy over the shadow order
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 }
 namespace ptk_strict_bvh {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 }
 // PTGPU_CULL_BALL: the hybrid fast build and the strict build with the point test compiled in
 namespace ptk_fast_ball {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 }
 namespace ptk_strict_ball {
 int work_counters(unsigned long long *out, int reset); // -DPT_COUNT_WORK=1 builds only
 int launch_mega(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
 int launch_wavefront(const PtDeviceParams &p, const PtLaunchConfig &c, hipStream_t s);
+int launch_probe(const PtDeviceParams &p, const PtRayProbe &r, hipStream_t s);
 }

@@ -1284,6 +1284,57 @@ int ptgpu_get_launch_info(ptgpu_ctx *ctx, ptgpu_launch_info *info) {
     return PTGPU_OK;
 }
 
+int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *directions, const float *maxt,
+                     float *t, float *rgb, int *occluded, int cooperative) {
+    int rc = bind(ctx);
+    if (rc) return rc;
+    if (n < 0 || (n > 0 && (!origins || !directions || !maxt || !t || !rgb || !occluded)))
+        return fail(PTGPU_ERR_ARGUMENT, "null argument");
+#if defined(PT_RAY_PROBE) && PT_RAY_PROBE
+    if (!ctx->d_prims) return fail(PTGPU_ERR_STATE, "no scene set");
+    if (n == 0) return PTGPU_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ImageTarget img = own_image(ctx); // (the launch parameters carry an image; the probe kernel does not touch it)
+    const PtDeviceParams p = make_params(ctx, img, 0, 1);
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t in_floats = 7 * (size_t)n, out_floats = 5 * (size_t)n;
+    HIP_TRY(hipMalloc((void **)&d_in, in_floats * sizeof(float)));
+    hipError_t e = hipMalloc((void **)&d_out, out_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_in, origins, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + 3 * (size_t)n, directions, 3 * (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_in + 6 * (size_t)n, maxt, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+    int launched = -1;
+    if (e == hipSuccess) {
+        PtRayProbe r;
+        r.n = n;
+        r.origin = d_in;
+        r.direction = d_in + 3 * (size_t)n;
+        r.maxt = d_in + 6 * (size_t)n;
+        r.t = d_out;
+        r.rgb = d_out + (size_t)n;
+        r.occluded = (int *)(d_out + 4 * (size_t)n);
+        r.cooperative = cooperative && p.n_bnodes;
+        const bool strict = ctx->math == PTGPU_MATH_STRICT;
+        launched = p.n_bnodes      ? (strict ? ptk_strict_bvh::launch_probe(p, r, ctx->stream) : ptk_fast_bvh::launch_probe(p, r, ctx->stream))
+                   : p.ball_groups ? (strict ? ptk_strict_ball::launch_probe(p, r, ctx->stream) : ptk_fast_ball::launch_probe(p, r, ctx->stream))
+                   : p.n_hnodes    ? ptk_fast_hyb::launch_probe(p, r, ctx->stream)
+                                   : (strict ? ptk_strict::launch_probe(p, r, ctx->stream) : ptk_fast::launch_probe(p, r, ctx->stream));
+        if (launched == 0) e = hipStreamSynchronize(ctx->stream);
+        if (launched == 0 && e == hipSuccess) e = hipMemcpy(t, d_out, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+        if (launched == 0 && e == hipSuccess) e = hipMemcpy(rgb, d_out + (size_t)n, 3 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+        if (launched == 0 && e == hipSuccess) e = hipMemcpy(occluded, d_out + 4 * (size_t)n, (size_t)n * sizeof(int), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess || launched != 0) return fail(PTGPU_ERR_DEVICE, "the ray probe failed");
+    return PTGPU_OK;
+#else
+    (void)cooperative;
+    return fail(PTGPU_ERR_STATE, "this libptgpu.so is not the ray-probe build (scripts/build_variants.sh builds "
+                                 "path-tracer_amd/variants/libptgpu_probe.so with -DPT_RAY_PROBE=1)");
+#endif
+}
+
 int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters, int reset) {
     int rc = bind(ctx);
     if (rc) return rc;

@@ -243,7 +243,7 @@ GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_s
                "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
                "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
                "ptgpu_shadow_candidates", "ptgpu_last_error", "ptgpu_render_static",
-               "ptgpu_get_launch_info", "ptgpu_work_counters"]
+               "ptgpu_get_launch_info", "ptgpu_work_counters", "ptgpu_probe_rays"]
 
 
 class LaunchInfo(C.Structure):
@@ -315,6 +315,7 @@ def _bind(lib):
     lib.ptgpu_shadow_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.POINTER(C.c_uint32)]
     lib.ptgpu_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
     lib.ptgpu_work_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
+    lib.ptgpu_probe_rays.argtypes = [vp, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
     return lib
 
 
@@ -515,6 +516,19 @@ class Gpu:
         out = (C.c_ulonglong * 16)()
         self._ok(self.lib.ptgpu_work_counters(self.ctx, out, 1 if reset else 0))
         return {n: int(out[i]) for i, n in enumerate(WORK_SLOTS)}
+
+    def probe_rays(self, origins, directions, maxt, cooperative=False):
+        """Ray-probe build only (lib=variant_path("probe")): closest hit and occlusion answer of the rays given
+        (n x 3, n x 3, n).  Returns t (-1: no hit), rgb of the surface hit (colour + emission), occluded (bool)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        m = np.ascontiguousarray(maxt, dtype=np.float32).reshape(-1)
+        n = len(o)
+        assert len(d) == n and len(m) == n
+        t = np.empty(n, np.float32); rgb = np.empty((n, 3), np.float32); occ = np.empty(n, np.int32)
+        self._ok(self.lib.ptgpu_probe_rays(self.ctx, n, _ptr(o), _ptr(d), _ptr(m), _ptr(t), _ptr(rgb), _ptr(occ),
+                                           1 if cooperative else 0))
+        return t, rgb, occ.astype(bool)
 
     def close(self):
         if self.ctx:

@@ -6,6 +6,8 @@
 #   libptgpu_giveup.so  -DPT_QUEUE_SPIN_LIMIT=0: a work-queue wave that has to wait for a tile's previous
 #                       chunk gives up at once (tests/test_gpu_synthetic.py checks that ptgpu_finish
 #                       reports it and that the context stays usable).
+#   libptgpu_probe.so   -DPT_RAY_PROBE=1: ptgpu_probe_rays traces rays the caller names through each code
+#                       instance's intersection routines (tests/test_gpu_rays.py: tie rule, hierarchy walks).
 set -e
 cd "$(dirname "$0")/../path-tracer_amd/csrc"
 mkdir -p ../variants
@@ -26,4 +28,5 @@ build() { # name flags
 }
 build count "-DPT_COUNT_WORK=1"
 build giveup "-DPT_QUEUE_SPIN_LIMIT=0"
-ls -la ../variants/libptgpu_count.so ../variants/libptgpu_giveup.so
+build probe "-DPT_RAY_PROBE=1"
+ls -la ../variants/libptgpu_count.so ../variants/libptgpu_giveup.so ../variants/libptgpu_probe.so

@@ -296,7 +296,9 @@ int ptgpu_work_counters(ptgpu_ctx *ctx, unsigned long long *counters /* [PTGPU_W
  * checked ray by ray (tests/test_gpu_rays.py).  origins / directions: 3 floats per ray (directions as the path
  * loop would pass them: normalised); maxt: 1 float per ray; t: distance of the closest hit or -1; rgb: colour +
  * emission of the surface hit; occluded: 1 if anything is hit between EPSILON and maxt.  cooperative != 0: where a
- * hierarchy is walked, through the wavefront kernel's wave-cooperative walks.  Needs a scene and a frame
+ * hierarchy is walked, through the wavefront kernel's wave-cooperative walks; cooperative == 2 (fast build with ray
+ * bins): occluded = bit 0 the face-plane test of the scene's closed convex clusters, bit 1 the any-hit scan over the
+ * same clusters' triangles (t and rgb untouched).  Needs a scene and a frame
  * (ptgpu_resize).  Only in the ray-probe build of the library (-DPT_RAY_PROBE=1, path-tracer_amd/variants/
  * libptgpu_probe.so); elsewhere it returns PTGPU_ERR_STATE. */
 int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *directions, const float *maxt,

@@ -1313,7 +1313,7 @@ int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *d
         r.t = d_out;
         r.rgb = d_out + (size_t)n;
         r.occluded = (int *)(d_out + 4 * (size_t)n);
-        r.cooperative = cooperative && p.n_bnodes;
+        r.cooperative = cooperative == 2 ? (p.n_clusters && p.convex_counts ? 2 : 0) : (cooperative && p.n_bnodes);
         const bool strict = ctx->math == PTGPU_MATH_STRICT;
         launched = p.n_bnodes      ? (strict ? ptk_strict_bvh::launch_probe(p, r, ctx->stream) : ptk_fast_bvh::launch_probe(p, r, ctx->stream))
                    : p.ball_groups ? (strict ? ptk_strict_ball::launch_probe(p, r, ctx->stream) : ptk_fast_ball::launch_probe(p, r, ctx->stream))

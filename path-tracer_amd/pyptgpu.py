@@ -527,8 +527,8 @@ class Gpu:
         assert len(d) == n and len(m) == n
         t = np.empty(n, np.float32); rgb = np.empty((n, 3), np.float32); occ = np.empty(n, np.int32)
         self._ok(self.lib.ptgpu_probe_rays(self.ctx, n, _ptr(o), _ptr(d), _ptr(m), _ptr(t), _ptr(rgb), _ptr(occ),
-                                           1 if cooperative else 0))
-        return t, rgb, occ.astype(bool)
+                                           int(cooperative)))
+        return t, rgb, (occ if int(cooperative) == 2 else occ.astype(bool))
 
     def close(self):
         if self.ctx:

@@ -78,3 +78,34 @@ def test_hierarchy_walks_answer_as_the_linear_scan_ray_by_ray(name):
             assert (tree[0].view(np.uint32) == lin[0].view(np.uint32)).all(), (name, math, cooperative, "distance bits")
             assert (tree[1] == lin[1]).all(), (name, math, cooperative, "surface")
             assert (tree[2] == lin[2]).all(), (name, math, cooperative, "occlusion")
+
+
+def test_face_plane_test_of_convex_clusters_answers_as_their_triangles_ray_by_ray():
+    # The near batches of the fast build test a closed convex cluster by its face planes (radiance_device.inc,
+    # segment_crosses_convex).  Ray by ray against the any-hit scan over the same clusters' triangles: random
+    # segments through the room, and segments that START ON the meshes (a diffuse mesh starts its shadow rays on
+    # itself), leaving outwards and diving inwards.  The two may differ only for a ray that grazes an edge within
+    # rounding: none of these does.
+    from test_gpu_synthetic import convex_scene
+    rng = np.random.default_rng(5)
+    for sc, boxes in ((make_scene(convex_scene(), 8, 8), [((-10, 0, 60), (10, 22, 80))]),
+                      (pt.LoadedScene("cornell", 8, 8), [])):
+        n = 20000
+        o, d, maxt = random_rays(n, 3)
+        if boxes:                                   # origins on the faces of the cube, any direction
+            (x0, y0, z0), (x1, y1, z1) = boxes[0]
+            p = rng.uniform((x0, y0, z0), (x1, y1, z1), (n // 2, 3))
+            face = rng.integers(0, 6, n // 2)
+            for a in range(3):
+                p[face == 2 * a, a] = (x0, y0, z0)[a]
+                p[face == 2 * a + 1, a] = (x1, y1, z1)[a]
+            o[: n // 2] = p.astype(np.float32)
+        g = pt.Gpu(0, 0, lib=pt.variant_path("probe"), math=pt.MATH_FAST)
+        g.set_scene(sc)
+        g.resize(8, 8, pt.seed_block(8, 8))
+        assert g.scene_info()["convex_clusters"] >= 1
+        _, _, bits = g.probe_rays(o, d, maxt, cooperative=2)
+        g.close()
+        planes, tris = (bits & 1) != 0, (bits & 2) != 0
+        print(f"convex clusters: {tris.mean():.3f} of the segments cross one; plane test differs on {(planes != tris).sum()} of {n}")
+        assert tris.mean() > 0.02 and (planes != tris).mean() <= 1e-4

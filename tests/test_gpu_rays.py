@@ -109,3 +109,14 @@ def test_face_plane_test_of_convex_clusters_answers_as_their_triangles_ray_by_ra
         planes, tris = (bits & 1) != 0, (bits & 2) != 0
         print(f"convex clusters: {tris.mean():.3f} of the segments cross one; plane test differs on {(planes != tris).sum()} of {n}")
         assert tris.mean() > 0.02 and (planes != tris).mean() <= 1e-4
+
+
+def test_the_shipped_library_has_no_ray_probe():
+    g = pt.Gpu(0, 0)
+    g.set_scene(pt.LoadedScene("simple", 8, 8))
+    g.resize(8, 8, pt.seed_block(8, 8))
+    with pytest.raises(pt.GpuError, match="ray-probe build"):
+        g.probe_rays([[0, 0, 0]], [[0, 0, 1]], [1.0])
+    g.render(1)          # and the context is as usable as before
+    g.finish()
+    g.close()

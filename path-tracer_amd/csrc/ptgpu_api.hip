@@ -786,9 +786,12 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
     // the extra launches, so they stay on one stream with the passes looped inside the launch.
     const long long work = (long long)c->info.primitives * (1 + (long long)c->info.lights);
     const int regions = (c->n_streams > 1 && probe.n_tiles >= 2048 && work >= 128) ? c->n_streams : 1;
-    // Passes done inside one launch: with several regions in flight a launch may be short (its
-    // tail is covered by the other regions); a single region keeps 8 passes per launch.
-    const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 1 : 8);
+    // Passes done inside one launch (the image state stays in registers across them, and a launch costs what ten
+    // passes of caustic.txt do): 32 on one stream, 8 with several regions in flight - measured at 1024x768
+    // (scripts/passes_per_launch.py): caustic.txt 47.9 (8) -> 53.9 (32) Gpaths/s, its direct-lighting run 65.6 -> 74.4,
+    // cornell-large dl 28.2 -> 29.5; four regions with 1 / 8 passes per launch: materials dl 19.9 / 31.3, complex dl
+    // 13.9 / 17.7, table-and-mirror dl 12.1 / 14.7, cornell dl 3.62 / 3.72.
+    const int chunk = c->passes_per_launch > 0 ? c->passes_per_launch : (regions > 1 ? 8 : 32);
 
     // AUTO: the shadow-ray queues pay with two or more lights and incoherent hit points; the direct
     // lighting integrator stops at the (tile-coherent) first hit, where the inline loop is ahead.

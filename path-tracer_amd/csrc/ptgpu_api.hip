@@ -865,8 +865,15 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
     // traffic (one counter takes ~3e7 increments per second: every scene is capped at 1 920 Mpaths/s
     // with one-pass units): one pass for cornell.txt, 4 for obj-model, 16 for materials.txt
     // (6 843 -> 7 526 Mpaths/s with the queue, scripts/queue_units.py).
-    long long unit_passes = work > 0 ? (4096 + work - 1) / work : 16;
+    // (with a hierarchy a ray costs a walk, not a scan: the primitives outside it + 16 per level stand for the scene -
+    // complex.txt 3 -> 13 passes per unit: 2 583 -> 3 400 Mpaths/s, obj-model, table-and-mirror and large-object
+    // unchanged at 10, 8 and 12, scripts/queue_choice.py)
+    long long unit_work = work;
+    if (probe.n_bnodes > 0)
+        unit_work = (long long)(probe.n_brest + 16.0 * std::log2((double)probe.n_bslots + 1.0)) * (1 + (long long)c->info.lights);
+    long long unit_passes = unit_work > 0 ? (4096 + unit_work - 1) / unit_work : 16;
     unit_passes = unit_passes < 1 ? 1 : unit_passes > 16 ? 16 : unit_passes;
+    if (const char *dbg = getenv("PTGPU_DEBUG_UNIT_PASSES")) unit_passes = atoi(dbg) > 0 ? atoi(dbg) : unit_passes; // (measurement aid)
     if (unit_passes > n_passes) unit_passes = n_passes;
     // (Wavefront kernel only; AUTO: under the path-tracing integrator, where the rule above was
     // measured.  The mega kernel's scenes and the direct-lighting integrator are an order of magnitude

@@ -100,7 +100,7 @@ enum {
  *   TIGHT also culls primitives that touch the plane from behind (closed half-space, tolerance
  *         1e-5 relative): exact in real arithmetic; in floating point a ray grazing the light's
  *         plane within rounding distance may see a different occluder than upstream.
- *   ENCLOSED  TIGHT, and a sphere that is not a dielectric leaves the set of every triangle light
+ *   ENCLOSED  TIGHT, and a sphere that is not a dielectric leaves the set of every light - triangle or sphere -
  *         that lies wholly inside it (the r = 1e4 wall spheres of the upstream scenes): a segment
  *         between two points of a ball stays in the ball, and a path that starts inside such a
  *         sphere never leaves it (it is opaque), so in real arithmetic the sphere cannot occlude.

@@ -113,6 +113,7 @@ struct ptgpu_ctx {
     int n_bnodes = 0, n_bslots = 0, n_brest = 0, bvh_type = 0;
     bool bvh_auto = false;             // AUTO turns it on for this scene
     bool bvh_auto_exact = false; // a hierarchy worth walking exists, candidate sets or not
+    bool sets_tight_pay = false; // the SAFE / TIGHT sets cull enough to be worth their masks (else only ENCLOSED's do)
     float4 *d_hyb_nodes = nullptr;     // hierarchy over the shadow order (hybrid)
     int n_hnodes = 0;
     uint32_t lds_fast_hyb = 0;
@@ -274,6 +275,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
             if (!(std::sqrt(dx * dx + dy * dy + dz * dz) <= (double)s.w * (1 - kEnclosedMargin) - 1.0)) cull = PTGPU_CULL_TIGHT;
         }
     }
+    if ((cull == PTGPU_CULL_SAFE || cull == PTGPU_CULL_TIGHT) && !c->sets_tight_pay) cull = PTGPU_CULL_OFF;
     p.sprims = c->d_sprims;
     p.sshade = c->d_sshade;
     p.smask = cull == PTGPU_CULL_SAFE       ? c->d_smask_safe
@@ -401,8 +403,23 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
         const D3 p0 = d3(lights[4 * l]), e1 = d3(lights[4 * l + 1]), e2 = d3(lights[4 * l + 2]);
         D3 n = cross(e1, e2);
         const double nn = len(n), size = len(e1) + len(e2);
-        // one-sided triangle lights with a usable normal; every other light keeps every primitive
-        if (light_type != PT_TRIANGLE || !std::isfinite(nn) || !(nn > 1e-12 * size * size)) continue;
+        // one-sided triangle lights with a usable normal; every other light keeps every primitive - except, under
+        // ENCLOSED, the opaque spheres a SPHERE light lies strictly inside (the wall spheres of the sphere-lit
+        // rooms: cornell-large.txt, cornell-original.txt, materials.txt ...): the same rule, the same reason
+        if (light_type != PT_TRIANGLE || !std::isfinite(nn) || !(nn > 1e-12 * size * size)) {
+            if (enclosed_rule && light_type == PT_SPHERE) {
+                const double rl = std::fabs((double)lights[4 * l + 1].x);
+                for (size_t i = 0; i < n_prims; ++i) {
+                    if (types[i] != PT_SPHERE || dielectric[i]) continue;
+                    const double r = std::fabs((double)prims[3 * i].w);
+                    if (len(sub(d3(prims[3 * i]), p0)) + rl <= r * (1 - kEnclosedMargin)) { // (a NaN keeps it)
+                        encloses[i] = 1;
+                        keep[l * n_prims + i] = 0;
+                    }
+                }
+            }
+            continue;
+        }
         ruled[l] = 1;
         n = {n.x / nn, n.y / nn, n.z / nn};
         // `h` = height of a point of the primitive above the light's plane, `reach` = its distance
@@ -1141,7 +1158,10 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     std::vector<float4> sshade;
     for (int slot : st.prim_of_slot)
         for (int q = 0; q < 4; ++q) sshade.push_back(slot >= 0 ? shade[4 * slot + q] : make_float4(0.f, 0.f, 0.f, 0.f));
-    const bool use_tables = st.tables_built && info.lights > 0 && st.mean_tight <= 0.9 * info.primitives;
+    // the tables are used when a mode culls a tenth of the primitives or more: SAFE / TIGHT by the TIGHT figure (the
+    // gate of round 1), ENCLOSED also by its own (the sphere-lit rooms, where only ENCLOSED culls: make_params)
+    const bool tight_pays = st.mean_tight <= 0.9 * info.primitives;
+    const bool use_tables = st.tables_built && info.lights > 0 && (tight_pays || st.mean_enclosed <= 0.9 * info.primitives);
     info.shadow_groups = (uint32_t)(st.sg_sph + st.sg_tri);
     info.shadow_tests_safe = use_tables ? (float)st.mean_safe : (float)info.primitives;
     info.shadow_tests_tight = use_tables ? (float)st.mean_tight : (float)info.primitives;
@@ -1256,6 +1276,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     ctx->mw_sph = st.mw_sph;
     ctx->mw_tri = st.mw_tri;
     ctx->smask_levels = use_tables ? st.levels : 0;
+    ctx->sets_tight_pay = use_tables && tight_pays;
     ctx->lds_strict = lds_strict;
     ctx->lds_strict_cull = lds_strict_cull;
     ctx->lds_fast = lds_fast;

@@ -178,12 +178,18 @@ def test_shadow_cull_tight_equals_its_cpu_replay_bitwise(kernel):
 @pytest.mark.parametrize("kernel", KERNELS, ids=lambda k: KNAME[k])
 def test_shadow_cull_enclosed_equals_its_cpu_replay_and_falls_back_outside(kernel):
     # ENCLOSED (the fast build's default) is a fixed algorithm too: strict build == oracle replay
-    name, w, h, spp = "cornell", 96, 72, 3
-    sc = pt.LoadedScene(name, w, h)
-    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_ENCLOSED)):
-        cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
-    colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_ENCLOSED)
-    assert (sd == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all()
+    # (cornell-large.txt: a SPHERE light inside the six wall spheres - the rule drops them for it too, and there the
+    # ENCLOSED sets are the only ones that cull anything: the tables exist for their sake)
+    for name, w, h, spp in (("cornell-large", 96, 72, 4), ("cornell", 96, 72, 3)):
+        sc = pt.LoadedScene(name, w, h)
+        sets = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
+        assert (sets == 0).sum() >= 6, name                      # the walls, at least
+        with ob.shadow_candidates(sets):
+            cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+        colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_ENCLOSED)
+        assert (sd == cpu.seeds).all() and same_bits(colors, cpu.colors) and (pixels == cpu.pixels).all(), name
+        plain = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT)
+        assert not same_bits(colors, plain[0]), name              # and the sets were in use: the walls' acne is gone
     # a camera outside the walls: paths are no longer inside the spheres the rule dropped, and the
     # library renders with the TIGHT sets (bit-identical to asking for TIGHT)
     out = []

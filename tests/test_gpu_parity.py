@@ -567,8 +567,8 @@ def test_full_size_properties_cornell_1024x768():
         q.close()
 
 
-def _fast_against_strict(w, h, spp, cull):
-    sc = pt.LoadedScene("cornell", w, h)
+def _fast_against_strict(w, h, spp, cull, scene="cornell"):
+    sc = pt.LoadedScene(scene, w, h)
     seeds = pt.seed_block(w, h)
     out = []
     for math, c in ((pt.MATH_FAST, cull), (pt.MATH_STRICT, pt.CULL_SAFE)):
@@ -615,6 +615,20 @@ def test_headline_build_has_no_bias_beyond_its_candidate_sets(size):
           f"blocks p99 {np.quantile(blocks, .99):.4f} mean {blocks.mean():.5f}")
     assert (bias >= -0.5e-4).all() and (bias <= 3e-4).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
     assert np.quantile(blocks, .99) <= 0.015 and blocks.mean() <= 3e-3
+
+
+def test_config5_scene_enclosed_rule_for_its_sphere_light_moves_the_image_by_the_walls_acne_only():
+    """cornell-large.txt (BASELINE config 5's scene; one sphere light inside six wall spheres) at 1024x768x8:
+    fast math with the plain scan (TIGHT culls nothing here, so the library scans everything): |bias| <= 1e-4 per
+    channel (measured +3e-5, noise 2e-5); the default, ENCLOSED for the sphere light: one-signed, 0 .. +4e-4
+    (measured +1.3e-4 .. +2.4e-4: the acne of the six walls, as on cornell.txt); relative RMSE <= 5 %."""
+    w, h, spp = 1024, 768, 8
+    bias, rel_rmse, nan, _ = _fast_against_strict(w, h, spp, pt.CULL_TIGHT, "cornell-large")
+    print(f"cornell-large fast + plain scan vs strict: bias {bias}, rel rmse {rel_rmse:.4f}")
+    assert (np.abs(bias) <= 1e-4).all() and rel_rmse <= 0.05 and nan[0] == nan[1]
+    bias, rel_rmse, nan, _ = _fast_against_strict(w, h, spp, pt.CULL_ENCLOSED, "cornell-large")
+    print(f"cornell-large fast + ENCLOSED vs strict: bias {bias}, rel rmse {rel_rmse:.4f}")
+    assert (bias >= 0).all() and (bias <= 4e-4).all() and rel_rmse <= 0.05 and nan[0] == nan[1]
 
 
 def test_c_host_cli_end_to_end(tmp_path):

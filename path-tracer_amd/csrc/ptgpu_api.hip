@@ -899,7 +899,11 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
     const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
                        (img.is_static || c->work_queue == 1 ||
                         (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT && probe.n_tiles >= 2048 &&
-                         unit_passes * work >= 512));
+                         (probe.n_bnodes > 0 || unit_passes < 16)));
+    // (without a hierarchy, a scene whose unit would need the cap of 16 passes and more is too cheap for the queue now
+    // that launches without it carry 8 passes on four region streams: materials.txt 7 126 with / 7 807 Mpaths/s
+    // without, simple-spheres.txt 11 267 / 12 065; stacked-spheres.txt, open to the sky and uneven from tile to tile,
+    // is the one scene that loses by it, 10 931 / 10 178 - nothing the library knows at launch tells it apart)
     if (queue) {
         // The kernel numbers its units with an int: a call of more than kQueueMaxUnits units (4K frame,
         // some 8 000 one-pass chunks) is issued as several launches, in order on the stream.

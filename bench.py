@@ -218,7 +218,7 @@ def main():
     sc = pt.LoadedScene(args.scene, w, h)
     seeds = pt.seed_block(w, h, rank)
     culls = {"off": pt.CULL_OFF, "safe": pt.CULL_SAFE, "tight": pt.CULL_TIGHT, "enclosed": pt.CULL_ENCLOSED,
-             "ball": pt.CULL_BALL, "auto": pt.CULL_AUTO}
+             "ball": pt.CULL_BALL, "self": pt.CULL_ENCLOSED_SELF, "auto": pt.CULL_AUTO}
 
     def make_gpu(math=None, cull=None, lib=None):
         return pt.Gpu(local_rank, pt.INTEGRATOR_PT if args.integrator == "pt" else pt.INTEGRATOR_DL,

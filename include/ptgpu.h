@@ -20,6 +20,7 @@
 #define PTGPU_H
 
 #include "pt_records.h"
+#include "pt_enclosed.h" /* pt_enclosed_inside_limit: "well inside" for the ENCLOSED family of candidate sets */
 
 #ifdef __cplusplus
 extern "C" {
@@ -101,13 +102,24 @@ enum {
  *         1e-5 relative): exact in real arithmetic; in floating point a ray grazing the light's
  *         plane within rounding distance may see a different occluder than upstream.
  *   ENCLOSED  TIGHT, and a sphere that is not a dielectric leaves the set of every light - triangle or sphere -
- *         that lies wholly inside it (the r = 1e4 wall spheres of the upstream scenes): a segment
- *         between two points of a ball stays in the ball, and a path that starts inside such a
- *         sphere never leaves it (it is opaque), so in real arithmetic the sphere cannot occlude.
- *         Upstream's float discriminant can still report the sphere a ray starts on ("acne":
- *         1e-4 of cornell.txt's radiance, scripts/wall_sphere_shadow.py) - rounding-level, like
- *         TIGHT's grazing rays.  The library checks at every launch that the camera is inside
- *         every sphere this rule dropped, and renders with the TIGHT sets when it is not.
+ *         that lies wholly inside it (the r = 1e4 wall spheres of the upstream scenes), FOR THE RAYS THAT START
+ *         WELL INSIDE IT: a segment between two points of a ball stays in the ball, so the sphere cannot occlude
+ *         such a ray, in real arithmetic or in upstream's float test (the origin's depth below the surface,
+ *         pt_enclosed_inside_limit, is far above the rounding of the discriminant).  Whether a path vertex is well
+ *         inside is CHECKED, per vertex and dropped sphere (one squared distance each): upstream's paths do leave
+ *         their room - a bounce ray that starts within EPSILON of a second wall passes through it (t > EPSILON,
+ *         geomfunc.h:36) and lands outside, where every light is occluded by that wall; round 2 assumed they
+ *         could not, and that assumption was the whole one-signed deviation of this mode (+1.2e-4 of cornell.txt's
+ *         radiance: 0.06 % of the vertices, fully lit instead of dark).  A vertex that is not well inside a dropped
+ *         sphere keeps that sphere for its shadow rays.  The one sphere NOT kept that way is the sphere the vertex
+ *         stands on: upstream's discriminant can report it for grazing rays ("acne"; their cosine, and with it
+ *         their weight, is ~0: 1e-6 of the radiance, no sign).  At most 32 spheres are dropped per scene.
+ *         The library also checks at every launch that the camera is inside every sphere this rule dropped,
+ *         and renders with the TIGHT sets when it is not.
+ *   ENCLOSED_SELF  ENCLOSED, and a shadow ray is also tested against the dropped sphere its origin stands on
+ *         (upstream's SphereIntersect on upstream's operands, geomfunc.h:10-39, per lane): with it every
+ *         occlusion answer is TIGHT's, bit for bit in the strict build, for one more sphere test per shadow ray
+ *         that starts on a wall.
  *   BALL  (opt-in) ENCLOSED, and where such a sphere (one that encloses some light) is still in the
  *         set of a triangle light that reaches out of it, its ray test is replaced by a test of
  *         one point: the ray starts inside the ball, so it crosses the sphere before maxt exactly
@@ -122,7 +134,7 @@ enum {
  *   AUTO  = SAFE under PTGPU_MATH_STRICT, ENCLOSED under PTGPU_MATH_FAST. */
 enum {
     PTGPU_CULL_OFF = 0, PTGPU_CULL_SAFE = 1, PTGPU_CULL_TIGHT = 2, PTGPU_CULL_AUTO = 3, PTGPU_CULL_ENCLOSED = 4,
-    PTGPU_CULL_BALL = 5
+    PTGPU_CULL_BALL = 5, PTGPU_CULL_ENCLOSED_SELF = 6
 };
 enum {
     PTGPU_MATH_FAST   = 0, /* FMA contraction on, v_rcp/v_rsq/v_sqrt/v_sin/v_cos f32 approximations:
@@ -306,11 +318,13 @@ int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *d
 
 /* The candidate sets behind PTGPU_OPT_SHADOW_CULL as plain data (host only, no device needed; no
  * reference counterpart - the reference scans every object, geomfunc.h:162-193).  For the scene
- * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT, ENCLOSED or BALL (OFF:
- * all ones; ENCLOSED and BALL as if the camera were inside every sphere the rule relies on),
+ * ptgpu_set_scene would stage from the same arguments and mode SAFE, TIGHT, ENCLOSED, BALL or ENCLOSED_SELF (OFF:
+ * all ones; the ENCLOSED family as if the camera were inside every sphere the rule relies on),
  * keep[l * object_count + i] = 1 when object i is scanned for a shadow ray towards the l-th light
  * (sampling order), 0 when it is culled or is not a sphere/triangle, 2 (BALL) when sphere i is
- * tested by the ray's point at maxt instead of the ray.  *n_lights receives the number
+ * tested by the ray's point at maxt instead of the ray, 4 (the ENCLOSED family) when sphere i is tested only by the
+ * rays whose origin is not well inside it (pt_enclosed_inside_limit) and does not lie on it, 3 (ENCLOSED_SELF)
+ * likewise but including the rays that start on it.  *n_lights receives the number
  * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the
  * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves.
  * No material table is passed: an object counts as a dielectric (it encloses nothing) when its
@@ -319,6 +333,15 @@ int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *d
  * glass in another slot the sets staged on the device can be larger than the ones returned here. */
 int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uint32_t light_count,
                             int mode, uint8_t *keep, uint32_t *n_lights);
+
+/* The triangle clusters behind PTGPU_OPT_RAY_BINS as plain data (host only, no device needed; no reference
+ * counterpart): *clusters = the clusters ptgpu_set_scene would bin shadow rays on for these objects (connected
+ * components of the meshes, the 8 largest with >= 8 triangles), convex_planes_per_cluster[c] (8 entries) = the
+ * face planes cluster c is tested by when it is a closed convex mesh WITH A VOLUME (4 .. 15 planes), 0 when it keeps
+ * its triangles.  Used by the tests: a flat double-sided polygon is closed by the edge count and convex by the vertex
+ * test, and must still keep its triangles. */
+int ptgpu_cluster_info(const pt_object *objects, uint32_t object_count, uint32_t light_count, uint32_t *clusters,
+                       uint32_t *convex_planes_per_cluster);
 
 const char *ptgpu_last_error(void);
 

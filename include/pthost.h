@@ -100,6 +100,42 @@ int pthost_checkpoint_write(const char *path, int width, int height, int current
 int pthost_checkpoint_read(const char *path, int *width, int *height, int *current_sample,
                            float **colors, uint32_t **seeds);
 
+/* ---- interactive input, headless -------------------------------------------------------
+ * What the reference's GLUT callbacks do to the camera, the sample counter and the image buffers, as plain
+ * functions over a state record: no window, the caller feeds the events (ptcli --script, the tests).  Every
+ * function returns a mask of PTHOST_EV_*: what the caller has to do before the next frame.
+ *   CAMERA    reInitViewpointDependentBuffers(0), main-gpu.c:885-913: `camera` (basis recomputed) is to be
+ *             uploaded (ptgpu_set_camera) and the sample counter reset to 0
+ *   REALLOC   reInitViewpointDependentBuffers(1), main-gpu.c:887-890: the image buffers are re-allocated at
+ *             width x height with fresh rand() seeds (pthost_input_next_seeds + ptgpu_resize); comes with CAMERA
+ *   SNAPSHOT  the 'p' key: write the PPM (pthost_snapshot_name + pthost_write_ppm)
+ *   QUIT      ESC */
+enum { PTHOST_EV_NONE = 0, PTHOST_EV_CAMERA = 1, PTHOST_EV_REALLOC = 2, PTHOST_EV_SNAPSHOT = 4, PTHOST_EV_QUIT = 8 };
+typedef struct pthost_input {
+    pt_camera camera;            /* the reference's global `camera`, basis up to date */
+    pt_camera original_camera;   /* `originalCamera`, displayfunc.c:45, 135: what ' ' restores */
+    unsigned char key_states[256]; /* displayfunc.c:42 */
+    int shift_pressed, mouse_button, mouse_x, mouse_y, time_before; /* displayfunc.c:40-46 */
+    int width, height;           /* window size (displayfunc.c:34-35); camera.width / height keep the first size */
+    unsigned long long rand_consumed; /* rand() outputs drawn so far by seed (re)allocations */
+} pthost_input;
+/* State after main() has run readScene, updateCameraBasis and setUpOpenCL (main-gpu.c:948-956): `loaded_camera` as
+ * pthost_load_scene left it, the first seed block (2*W*H rand() outputs) drawn. */
+void pthost_input_init(pthost_input *in, const pt_camera *loaded_camera, int width, int height);
+/* update() up to its updateRendering() call, displayfunc.c:450-453 + updateCamera :408-444: WASD held down move
+ * `orig` and `target` along dir / x by delta * 1e-4 (x 10 with shift); time_now_ms = glutGet(GLUT_ELAPSED_TIME). */
+int pthost_input_idle(pthost_input *in, int time_now_ms);
+int pthost_input_keyboard(pthost_input *in, unsigned char key);     /* displayfunc.c:496-592 */
+int pthost_input_keyboard_up(pthost_input *in, unsigned char key);  /* displayfunc.c:600-622 */
+int pthost_input_shift(pthost_input *in, int pressed);              /* displayfunc.c:661-671 */
+int pthost_input_mouse(pthost_input *in, int button, int x, int y); /* displayfunc.c:653-659 */
+int pthost_input_motion(pthost_input *in, int x, int y);            /* displayfunc.c:628-650: yaw / pitch by 0.01 rad per pixel */
+int pthost_input_reshape(pthost_input *in, int new_width, int new_height); /* displayfunc.c:482-493 */
+/* The seeds of the (re)allocated buffers, 2 * width * height words: the next block of the process's rand() stream
+ * (main-gpu.c:91-96).  GLUT fires reshape when the window is created, so an interactive run of the reference renders
+ * with the SECOND block; a run that never reshapes (this library's headless default) with the first. */
+void pthost_input_next_seeds(pthost_input *in, uint32_t *seeds);
+
 const char *pthost_last_error(void);
 
 #ifdef __cplusplus

@@ -69,11 +69,19 @@ void oracle_render_pass_counted(const pt_object *objects, uint32_t n, uint32_t l
 /* Replays the product's shadow-ray culling in the restatement (NOT part of the reference; NULL,
  * the default, is the reference's full scan): keep[l * n + i] = 0 makes the any-hit scan of a
  * shadow ray towards the l-th light skip object i; 2 (PTGPU_CULL_BALL, spheres only) replaces the
- * ray test of object i by "the ray's point at maxt lies outside the sphere".  The matrix comes from
+ * ray test of object i by "the ray's point at maxt lies outside the sphere"; 4 (the ENCLOSED family) keeps
+ * the test of sphere i for the rays whose origin is not well inside it (pt_enclosed_inside_limit) and does not
+ * lie on it, 3 (PTGPU_CULL_ENCLOSED_SELF) also for the rays that start on it.  The matrix comes from
  * ptgpu_shadow_candidates (include/ptgpu.h) with the same objects and light count as the renders
  * that follow; the caller keeps it alive until it is reset.  Used to prove on the CPU that a cull
  * mode leaves every bit of the image alone, and to count the tests the culled algorithm performs. */
 void oracle_set_shadow_candidates(const uint8_t *keep);
+
+/* Diagnostic of that replay (serial renders: threads <= 1): every shadow ray whose culled scan answers differently
+ * from the full scan is logged, 12 floats a record - origin xyz, direction xyz, maxt, light (sampling order), the
+ * object the ray starts on, the first object the full scan reports, its distance, the culled answer. */
+void oracle_set_mismatch_log(float *records, int capacity);
+int  oracle_mismatch_count(void);
 
 int oracle_max_threads(void);
 

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include "pt_oracle.h"
+#include "pt_enclosed.h" /* one definition of "well inside", shared with the product, for the replay of its sets */
 
 #define PI_F 3.14159265358979323846f
 #define TWO_PI_F 6.28318530717958647693f
@@ -81,6 +82,18 @@ uint32_t oracle_accumulate(pt_vec3 *color, const pt_vec3 *sample, int current_sa
 static const uint8_t *g_shadow_keep = NULL;
 void oracle_set_shadow_candidates(const uint8_t *keep) { g_shadow_keep = keep; }
 
+/* Diagnostic of the replay (serial renders only): every shadow ray whose culled scan answers differently
+ * from the reference's full scan is logged - origin, direction, maxt, light (sampling order), the object the
+ * ray starts on, the first object the full scan reports, its distance: 12 floats a record. */
+static float *g_mismatch_log = NULL;
+static int g_mismatch_capacity = 0, g_mismatch_count = 0;
+void oracle_set_mismatch_log(float *records, int capacity) {
+    g_mismatch_log = records;
+    g_mismatch_capacity = capacity;
+    g_mismatch_count = 0;
+}
+int oracle_mismatch_count(void) { return g_mismatch_count; }
+
 /* ---- instance 1: plain ---- */
 #define FN(name) plain_##name
 #define TALLY(field) ((void)0)
@@ -130,13 +143,13 @@ int oracle_intersect(const pt_object *objects, uint32_t n, const pt_ray *ray, fl
 }
 
 int oracle_intersect_p(const pt_object *objects, uint32_t n, const pt_ray *ray, float maxt) {
-    return plain_any_hit(objects, n, ray, maxt, NULL);
+    return plain_any_hit(objects, n, ray, maxt, NULL, UINT32_MAX);
 }
 
 void oracle_sample_lights(const pt_object *objects, uint32_t n, uint32_t lights, uint32_t *seed0,
                           uint32_t *seed1, const pt_vec3 *hit, const pt_vec3 *normal,
                           pt_vec3 *result) {
-    plain_direct_light(objects, n, lights, seed0, seed1, hit, normal, result);
+    plain_direct_light(objects, n, lights, seed0, seed1, hit, normal, UINT32_MAX, result);
 }
 
 void oracle_radiance(const pt_object *objects, uint32_t n, uint32_t lights, const pt_ray *ray,

@@ -81,20 +81,35 @@ static int FN(closest_hit)(const pt_object *objects, uint32_t n, const pt_ray *r
 /* geomfunc.h:162-193: any hit closer than maxt, early out in index order.
  * `candidates` (NULL upstream) replays the product's shadow-ray culling on the CPU: objects whose
  * byte is 0 are skipped, objects whose byte is 2 (spheres the ray starts inside of) are tested with
- * the ray's point at maxt instead of the ray (oracle_set_shadow_candidates). */
+ * the ray's point at maxt instead of the ray, objects whose byte is 3 or 4 (spheres) only by a ray whose origin is
+ * not well inside them - 3: or lies on them, 4: and does not lie on them (`origin_id` = the object the ray starts
+ * on; oracle_set_shadow_candidates). */
 static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
-                       float maxt, const uint8_t *candidates CTR_PARAM) {
+                       float maxt, const uint8_t *candidates, uint32_t origin_id CTR_PARAM) {
     TALLY(shadow_rays);
     for (uint32_t i = 0; i < n; i++) {
         float dist;
         if (candidates && !candidates[i]) continue;
-        if (candidates && candidates[i] == 2) {
-            /* PTGPU_CULL_BALL replay: the ray starts inside this sphere, so it crosses it before
-             * maxt exactly when its point at maxt lies outside (no ray test) */
-            const v3 end = v3_add(ray->o, v3_scale(maxt, ray->d));
-            const v3 off = v3_sub(end, objects[i].center);
-            if (v3_dot(off, off) > objects[i].radius * objects[i].radius) return 1;
-            continue;
+        /* the ENCLOSED family's replay (include/ptgpu.h).  A sphere the rule dropped (4), dropped but for the rays
+         * that start on it (3, ENCLOSED_SELF) or tests by the ray's end point (2, BALL) relies on the origin being
+         * well inside it; for an origin that is not - and does not stand on it - the ray is tested as upstream
+         * tests it.  The squared distance in float, as the kernels evaluate it. */
+        if (candidates && candidates[i] >= 2) {
+            int as_upstream = (candidates[i] == 3 && i == origin_id);
+            if (i != origin_id) {
+                const pt_object *s = &objects[i];
+                const float dx = ray->o.x - s->center.x, dy = ray->o.y - s->center.y, dz = ray->o.z - s->center.z;
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 < pt_enclosed_inside_limit(s->radius, s->center.x, s->center.y, s->center.z))) as_upstream = 1;
+            }
+            if (candidates[i] == 2) {
+                /* PTGPU_CULL_BALL replay: the ray starts inside this sphere, so it crosses it before
+                 * maxt exactly when its point at maxt lies outside (no ray test) */
+                const v3 end = v3_add(ray->o, v3_scale(maxt, ray->d));
+                const v3 off = v3_sub(end, objects[i].center);
+                if (v3_dot(off, off) > objects[i].radius * objects[i].radius) return 1;
+            }
+            if (!as_upstream) continue;
         }
         if (objects[i].type == PT_SPHERE)
             dist = FN(hit_sphere)(&objects[i], ray CTR_ARG);
@@ -113,7 +128,7 @@ static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
  * of them have been seen), draws two numbers per light BEFORE any rejection test, and adds
  * emission * area * wi * wo / len^2 for each unoccluded light facing the point.  No 1/N, no 1/pi. */
 static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t lights, uint32_t *s0,
-                             uint32_t *s1, const v3 *hit, const v3 *normal, v3 *result CTR_PARAM) {
+                             uint32_t *s1, const v3 *hit, const v3 *normal, uint32_t origin_id, v3 *result CTR_PARAM) {
     *result = v3_make(0.f, 0.f, 0.f);
     uint32_t seen = 0;
     for (uint32_t i = 0; i < n && seen < lights; i++) {
@@ -174,7 +189,28 @@ static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t ligh
         wo = clamp_macro(wo, 0.f, 1.f);
 
         const float wi = v3_dot(shadow.d, *normal);
-        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates CTR_ARG))) {
+#ifndef ORACLE_COUNTING
+        if (g_mismatch_log && candidates && (wi > 0.f)) { /* diagnostic: culled scan against the full scan */
+            const int culled = FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id CTR_ARG);
+            int full = 0;
+            uint32_t first = UINT32_MAX;
+            float first_t = 0.f;
+            for (uint32_t k = 0; k < n && !full; k++) {
+                float dist = 0.f;
+                if (objects[k].type == PT_SPHERE) dist = FN(hit_sphere)(&objects[k], &shadow CTR_ARG);
+                else if (objects[k].type == PT_TRIANGLE) dist = FN(hit_triangle)(&objects[k], &shadow CTR_ARG);
+                if ((dist != 0.f) && (dist < len - PT_EPSILON)) { full = 1; first = k; first_t = dist; }
+            }
+            if (culled != full && g_mismatch_count < g_mismatch_capacity) {
+                float *r = g_mismatch_log + 12 * (size_t)g_mismatch_count++;
+                r[0] = shadow.o.x; r[1] = shadow.o.y; r[2] = shadow.o.z;
+                r[3] = shadow.d.x; r[4] = shadow.d.y; r[5] = shadow.d.z;
+                r[6] = len - PT_EPSILON; r[7] = (float)(seen - 1); r[8] = (float)origin_id;
+                r[9] = (float)first; r[10] = first_t; r[11] = (float)culled;
+            }
+        }
+#endif
+        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id CTR_ARG))) {
             const float s = light->area * wi * wo / (len * len);
             const v3 contribution = v3_scale(s, light->emission);
             *result = v3_add(*result, contribution);
@@ -351,7 +387,7 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
             specular_bounce = 0;
             throughput = v3_mul(throughput, obj->color);
             v3 Ld;
-            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, &Ld CTR_ARG);
+            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, &Ld CTR_ARG);
             Ld = v3_mul(throughput, Ld);
             L = v3_add(L, Ld);
             if (integrator == PT_INTEGRATOR_DL) break;
@@ -373,7 +409,7 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
             const v3 f = FN(matte_factor)(m, ray.d, new_dir);
             throughput = v3_mul(throughput, f);
             v3 Ld;
-            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, &Ld CTR_ARG);
+            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, &Ld CTR_ARG);
             Ld = v3_mul(throughput, Ld);
             L = v3_add(L, Ld);
             if (integrator == PT_INTEGRATOR_DL) break;

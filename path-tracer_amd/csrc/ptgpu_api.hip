@@ -31,6 +31,20 @@ static __device__ __align__(256) int scratch[kStaticQueueWords];
 static constexpr int kMaxDevices = 64;
 static std::mutex g_static_mutex;
 static int *g_static_queue[kMaxDevices] = {}; // per device: address of ITS copy of `scratch`
+// the context whose ptgpu_render_static calls are in flight on the device's queue (null: free).  Calls of ONE context are
+// ordered on its stream and may follow each other; another context's call would zero a queue in flight, so it is
+// refused until the owner's ptgpu_finish (or a read-back, or its destruction) has seen the queue drained.
+static const void *g_static_owner[kMaxDevices] = {};
+static bool static_queue_claim(int device, const void *ctx) {
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (g_static_owner[device] && g_static_owner[device] != ctx) return false;
+    g_static_owner[device] = ctx;
+    return true;
+}
+static void static_queue_release(int device, const void *ctx) {
+    std::lock_guard<std::mutex> lock(g_static_mutex);
+    if (device >= 0 && device < kMaxDevices && g_static_owner[device] == ctx) g_static_owner[device] = nullptr;
+}
 
 // `device` must be the current device.  Allocates nothing: the array is part of the loaded code object.
 static int static_queue_of(int device, int **out) {
@@ -78,6 +92,9 @@ bool emits(const pt_vec3 &e) { return !((e.x == 0.f) && (e.x == 0.f) && (e.z == 
 
 } // namespace
 
+#ifndef PT_DEBUG_KNOBS
+#define PT_DEBUG_KNOBS 0 // getenv switches of the measurement scripts: compiled into the variant builds only
+#endif
 #ifndef PT_COOP_STRAGGLERS
 #define PT_COOP_STRAGGLERS 24 // measured 16 .. 48 on obj-model.txt, its bunny variant and large-object.txt
 #endif
@@ -106,6 +123,8 @@ struct ptgpu_ctx {
     unsigned long long *d_smask_safe = nullptr, *d_smask_tight = nullptr, *d_smask_enclosed = nullptr, *d_smask_ball = nullptr, *d_cmask = nullptr;
     unsigned ball_groups = 0;   // sphere groups some light tests by the ray's end point (PTGPU_CULL_BALL)
     std::vector<float4> enclosing; // (centre, radius) of the spheres PTGPU_CULL_ENCLOSED took out of a set
+    int *d_enc_index = nullptr, *d_enc_slot = nullptr; // those spheres in index order / as shadow-order slots (<= 32)
+    int n_enc = 0;
     float4 *d_cbounds = nullptr;
     // BVH (device_params.h): one block + the id tables in each build's numbering
     float4 *d_bvh = nullptr, *d_bvh_planes = nullptr; // (the fast build's copy: leaf triangles in plane form)
@@ -178,6 +197,10 @@ void free_scene(ptgpu_ctx *c) {
     if (c->d_smask_tight) (void)hipFree(c->d_smask_tight);
     if (c->d_smask_enclosed) (void)hipFree(c->d_smask_enclosed);
     if (c->d_smask_ball) (void)hipFree(c->d_smask_ball);
+    if (c->d_enc_index) (void)hipFree(c->d_enc_index);
+    if (c->d_enc_slot) (void)hipFree(c->d_enc_slot);
+    c->d_enc_index = c->d_enc_slot = nullptr;
+    c->n_enc = 0;
     c->d_sprims = nullptr;
     c->d_sprims_planes = nullptr;
     c->d_smask_safe = c->d_smask_tight = c->d_smask_enclosed = c->d_smask_ball = nullptr;
@@ -267,7 +290,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.n_launch_tiles = p.n_tiles;
     int cull = c->shadow_cull;
     if (cull == PTGPU_CULL_AUTO) cull = c->math == PTGPU_MATH_STRICT ? PTGPU_CULL_SAFE : PTGPU_CULL_ENCLOSED;
-    if (cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) {
+    if (cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL || cull == PTGPU_CULL_ENCLOSED_SELF) {
         // the rule holds for paths that start inside every sphere it dropped: camera rays leave from
         // orig + 0.1 rdir (main-cpu.c:76), |rdir| < 3 for any sane field of view, so one unit of margin
         for (const float4 &s : c->enclosing) {
@@ -281,8 +304,14 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.smask = cull == PTGPU_CULL_SAFE       ? c->d_smask_safe
               : cull == PTGPU_CULL_TIGHT    ? c->d_smask_tight
               : cull == PTGPU_CULL_ENCLOSED ? c->d_smask_enclosed
+              : cull == PTGPU_CULL_ENCLOSED_SELF ? c->d_smask_enclosed
               : cull == PTGPU_CULL_BALL     ? c->d_smask_ball
                                             : nullptr;
+    p.self_sphere = cull == PTGPU_CULL_ENCLOSED_SELF && p.smask ? 1 : 0;
+    // the spheres the ENCLOSED family dropped: every path vertex is checked against them (radiance_kernels.inc, vertex_needs)
+    const bool family = cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL || cull == PTGPU_CULL_ENCLOSED_SELF;
+    p.n_enc = family && p.smask ? c->n_enc : 0;
+    p.enc_list = c->math == PTGPU_MATH_STRICT ? c->d_enc_index : c->d_enc_slot;
     p.ball_groups = cull == PTGPU_CULL_BALL && p.smask ? c->ball_groups : 0u;
     p.n_sph_real = (int)c->info.spheres;
     p.sg_sph = c->sg_sph;
@@ -291,7 +320,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
     p.mw_tri = c->mw_tri;
     p.smask_levels = p.smask ? c->smask_levels : 0;
     // ray binning on triangle clusters: fast build, TIGHT sets only (the bins are built from them)
-    const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL) && p.smask &&
+    const bool bins = c->ray_bins && (cull == PTGPU_CULL_TIGHT || cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL || cull == PTGPU_CULL_ENCLOSED_SELF) && p.smask &&
                       c->math == PTGPU_MATH_FAST;
     p.n_clusters = bins ? c->n_clusters : 0;
     p.n_cquads = bins ? c->n_cquads : 0;
@@ -311,6 +340,8 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
 #endif
     if (use_bvh) { // the hierarchy replaces the candidate sets
         p.smask = nullptr;
+        p.self_sphere = 0;
+        p.n_enc = 0;
         p.ball_groups = 0;
         p.n_clusters = 0;
         p.n_cquads = 0;
@@ -352,6 +383,9 @@ struct ShadowTables {
     std::vector<unsigned long long> safe, tight, enclosed, ball;
     std::vector<unsigned> light_ball;                // per light: sphere groups tested by the ray's end point (BALL)
     std::vector<float4> enclosing;                   // spheres ENCLOSED dropped from at least one set
+    std::vector<uint8_t> self_flag;                  // per primitive: such a sphere (its record carries the "well inside"
+                                                     // limit in the second quad's .y; 0 elsewhere)
+    std::vector<int> enc_index, enc_slot;            // those spheres (<= 32) in index order / as shadow-order slots
     bool tables_built = false;
     int levels = 0;                                  // of the range table appended to safe / tight / enclosed / ball
     int sg_sph = 0, sg_tri = 0, mw_sph = 0, mw_tri = 0;
@@ -390,12 +424,24 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
                                        int mode) {
     const size_t n_prims = types.size(), n_lights = lights.size() / 4;
     std::vector<uint8_t> keep(n_lights * n_prims, 1);
-    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED && mode != PTGPU_CULL_BALL)
+    if (mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED && mode != PTGPU_CULL_BALL &&
+        mode != PTGPU_CULL_ENCLOSED_SELF)
         return keep;
-    const bool ball_rule = mode == PTGPU_CULL_BALL;
-    const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED || ball_rule;
+    const bool ball_rule = mode == PTGPU_CULL_BALL, self_rule = mode == PTGPU_CULL_ENCLOSED_SELF;
+    const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED || ball_rule || self_rule;
     if (enclosed_rule) mode = PTGPU_CULL_TIGHT;
     std::vector<uint8_t> encloses(n_prims, 0), ruled(n_lights, 0); // sphere i encloses some light; light l has sets
+    // the spheres the ENCLOSED rule may drop: opaque, with a usable "well inside" limit, the first 32 of them (the
+    // kernels keep, per path vertex, a bit per dropped sphere: is the vertex well inside it?)
+    std::vector<uint8_t> droppable(n_prims, 0);
+    if (enclosed_rule) {
+        int n = 0;
+        for (size_t i = 0; i < n_prims && n < 32; ++i) {
+            if (types[i] != PT_SPHERE || dielectric[i]) continue;
+            const float4 a = prims[3 * i];
+            if (pt_enclosed_inside_limit(a.w, a.x, a.y, a.z) > 0.f) { droppable[i] = 1; ++n; }
+        }
+    }
     const double eps = (double)PT_EPSILON;
     for (size_t l = 0; l < n_lights; ++l) {
         int light_type;
@@ -410,7 +456,7 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
             if (enclosed_rule && light_type == PT_SPHERE) {
                 const double rl = std::fabs((double)lights[4 * l + 1].x);
                 for (size_t i = 0; i < n_prims; ++i) {
-                    if (types[i] != PT_SPHERE || dielectric[i]) continue;
+                    if (!droppable[i]) continue;
                     const double r = std::fabs((double)prims[3 * i].w);
                     if (len(sub(d3(prims[3 * i]), p0)) + rl <= r * (1 - kEnclosedMargin)) { // (a NaN keeps it)
                         encloses[i] = 1;
@@ -434,7 +480,7 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
                 const double r = std::fabs((double)prims[3 * i].w);
                 all_behind = behind(dot(c, n) + r, len(c) + r);
                 // ENCLOSED: the light's three corners strictly inside an opaque sphere (a NaN keeps it)
-                if (enclosed_rule && !dielectric[i]) {
+                if (droppable[i]) {
                     const double inside = r * (1 - kEnclosedMargin);
                     if (len(c) <= inside && len(sub(c, e1)) <= inside && len(sub(c, e2)) <= inside) {
                         if (!all_behind) encloses[i] = 1; // what make_params checks the camera against
@@ -462,6 +508,13 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
         for (size_t l = 0; l < n_lights; ++l)
             for (size_t i = 0; i < n_prims; ++i)
                 if (ruled[l] && encloses[i] && keep[l * n_prims + i]) keep[l * n_prims + i] = 2;
+    // A sphere the rule took out of some light's set is still tested, whatever the light, by the rays whose origin is
+    // not well inside it (4; ptgpu.h: upstream's paths do leave their room through its corners) - under ENCLOSED_SELF
+    // also by the rays that start ON it (3)
+    if (enclosed_rule)
+        for (size_t l = 0; l < n_lights; ++l)
+            for (size_t i = 0; i < n_prims; ++i)
+                if (encloses[i] && !keep[l * n_prims + i]) keep[l * n_prims + i] = self_rule ? 3 : 4;
     return keep;
 }
 
@@ -591,6 +644,10 @@ std::vector<float4> convex_planes(const std::vector<float4> &prims, const std::v
         n = {n.x / nn, n.y / nn, n.z / nn};
         double w = dot(n, t[0]);
         if (dot(n, mid) > w) { n = {-n.x, -n.y, -n.z}; w = -w; }
+        // the centroid strictly inside: a flat, double-sided polygon (closed by the edge count, "convex" by the vertex
+        // test) has its centroid IN every face plane, the flip above is then decided by rounding, and what would come
+        // out bounds an infinite slab - a false occluder far outside the polygon
+        if (!(dot(n, mid) < w - tol)) return {};
         for (const D3 &v : verts)
             if (dot(n, v) > w + tol) return {};
         bool seen = false;
@@ -602,12 +659,14 @@ std::vector<float4> convex_planes(const std::vector<float4> &prims, const std::v
         planes.push_back(make_float4((float)n.x, (float)n.y, (float)n.z, (float)w));
         if ((int)planes.size() > kMaxConvexPlanes) return {};
     }
+    if (planes.size() < 4) return {}; // fewer planes bound no volume
     return planes;
 }
 
 void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int> &types,
                          const std::vector<float4> &lights, const std::vector<uint8_t> &dielectric, ShadowTables &t) {
     t.cluster_of = find_clusters(prims, types, t.cluster_bounds);
+    t.self_flag.assign(types.size(), 0);
     const int n_clusters = (int)t.cluster_bounds.size();
     // cluster table (device_params.h, cbounds): [bounds][planes of the convex clusters, cluster by cluster]; the plane
     // counts travel as a kernel argument, a nibble per cluster (LDS is short: cornell.txt's workgroup fits three to
@@ -635,12 +694,20 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
     t.tables_built = (double)n_lights * (double)n_prims <= (double)(1u << 26);
     std::vector<uint8_t> keep_enclosed;
     if (t.tables_built) {
-        // spheres that most lights still have to test come first, so that they share groups
+        // the spheres the ENCLOSED rule drops for some light come first (slot k = bit k of the per-vertex masks and of
+        // BALL's words: the kernels walk slots [0, n_enc) without an index table), then the others; within each
+        // class those that most lights still have to test first
         keep_enclosed = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_ENCLOSED);
         std::vector<size_t> users(n_prims, 0);
+        std::vector<uint8_t> dropped_somewhere(n_prims, 0);
         for (size_t l = 0; l < n_lights; ++l)
-            for (int i : sph_slots) users[i] += keep_enclosed[l * n_prims + i];
-        std::stable_sort(sph_slots.begin(), sph_slots.end(), [&](int a, int b) { return users[a] > users[b]; });
+            for (int i : sph_slots) {
+                users[i] += keep_enclosed[l * n_prims + i] == 1;
+                dropped_somewhere[i] |= keep_enclosed[l * n_prims + i] >= 3;
+            }
+        std::stable_sort(sph_slots.begin(), sph_slots.end(), [&](int a, int b) {
+            return dropped_somewhere[a] != dropped_somewhere[b] ? dropped_somewhere[a] > dropped_somewhere[b] : users[a] > users[b];
+        });
     }
     pad(sph_slots, kSphereGroup);
     // Triangle order = leaf order of a hierarchy whose leaves never mix clusters (bvh_build.h,
@@ -686,6 +753,7 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         t.cluster_masks[(size_t)(1 + cluster_of_group(g)) * t.mw_tri + g / 64] |= 1ull << (g % 64);
 
     const int words = t.mw_sph + t.mw_tri;
+    auto in_set = [](uint8_t k) { return k == 1 || k == 2; }; // (3, 4: only for the rays of a vertex not well inside)
     auto masks = [&](int mode, std::vector<unsigned long long> &out, double &mean) {
         const std::vector<uint8_t> keep = mode == PTGPU_CULL_ENCLOSED
                                               ? keep_enclosed
@@ -695,13 +763,13 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         double total = 0;
         for (size_t l = 0; l < n_lights; ++l) {
             for (size_t k = 0; k < sph_slots.size(); ++k)
-                if (sph_slots[k] >= 0 && keep[l * n_prims + sph_slots[k]]) {
+                if (sph_slots[k] >= 0 && in_set(keep[l * n_prims + sph_slots[k]])) {
                     out[l * words + (k / kSphereGroup) / 64] |= 1ull << ((k / kSphereGroup) % 64);
                     if (keep[l * n_prims + sph_slots[k]] == 2) // at most 32 spheres (shadow_candidates)
                         t.light_ball[l] |= 1u << (k / kSphereGroup);
                 }
             for (size_t k = 0; k < tri_slots.size(); ++k)
-                if (tri_slots[k] >= 0 && keep[l * n_prims + tri_slots[k]])
+                if (tri_slots[k] >= 0 && in_set(keep[l * n_prims + tri_slots[k]]))
                     out[l * words + t.mw_sph + (k / kTriGroup) / 64] |= 1ull << ((k / kTriGroup) % 64);
             for (int w = 0; w < words; ++w)
                 total += (w < t.mw_sph ? kSphereGroup : kTriGroup) * __builtin_popcountll(out[l * words + w]);
@@ -743,8 +811,23 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
         const std::vector<uint8_t> tight = shadow_candidates(prims, types, lights, dielectric, PTGPU_CULL_TIGHT);
         for (size_t i = 0; i < n_prims; ++i) {
             bool dropped = false;
-            for (size_t l = 0; l < n_lights && !dropped; ++l) dropped = tight[l * n_prims + i] && !keep_enclosed[l * n_prims + i];
+            for (size_t l = 0; l < n_lights && !dropped; ++l) dropped = tight[l * n_prims + i] && keep_enclosed[l * n_prims + i] >= 3; // (4: kept for the rays not well inside)
             if (dropped) t.enclosing.push_back(prims[3 * i]); // (centre, radius)
+            t.self_flag[i] = dropped && types[i] == PT_SPHERE;
+        }
+        // the dropped spheres, in each build's numbering, and their "well inside" limit in the record (second quad, .y)
+        for (size_t i = 0; i < n_prims; ++i)
+            if (t.self_flag[i]) t.enc_index.push_back((int)i);
+        for (size_t slot = 0; slot < t.prim_of_slot.size(); ++slot) {
+            const int i = t.prim_of_slot[slot];
+            if (i < 0 || !t.self_flag[i]) continue;
+            t.enc_slot.push_back((int)slot);
+            const float4 a = prims[3 * i];
+            const float lim = pt_enclosed_inside_limit(a.w, a.x, a.y, a.z);
+            float pre[4];
+            pt_enclosed_prefilter(a.w, a.x, a.y, a.z, lim, pre);
+            t.sprims[3 * slot + 1].y = t.sprims_planes[3 * slot + 1].y = lim;
+            t.sprims[3 * slot + 2] = t.sprims_planes[3 * slot + 2] = make_float4(pre[0], pre[1], pre[2], pre[3]);
         }
     }
 
@@ -869,7 +952,7 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
         li.shadow_cull = !p.smask                            ? PTGPU_CULL_OFF
                          : p.smask == c->d_smask_safe        ? PTGPU_CULL_SAFE
                          : p.smask == c->d_smask_tight       ? PTGPU_CULL_TIGHT
-                         : p.smask == c->d_smask_enclosed    ? PTGPU_CULL_ENCLOSED
+                         : p.smask == c->d_smask_enclosed    ? (p.self_sphere ? PTGPU_CULL_ENCLOSED_SELF : PTGPU_CULL_ENCLOSED)
                                                              : PTGPU_CULL_BALL;
         li.ray_bins = p.n_clusters > 0;
     };
@@ -890,7 +973,12 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
         unit_work = (long long)(probe.n_brest + 16.0 * std::log2((double)probe.n_bslots + 1.0)) * (1 + (long long)c->info.lights);
     long long unit_passes = unit_work > 0 ? (4096 + unit_work - 1) / unit_work : 16;
     unit_passes = unit_passes < 1 ? 1 : unit_passes > 16 ? 16 : unit_passes;
-    if (const char *dbg = getenv("PTGPU_DEBUG_UNIT_PASSES")) unit_passes = atoi(dbg) > 0 ? atoi(dbg) : unit_passes; // (measurement aid)
+#if PT_DEBUG_KNOBS // (measurement builds only, scripts/build_variants.sh: scripts/queue_units.py)
+    if (const char *dbg = getenv("PTGPU_DEBUG_UNIT_PASSES")) unit_passes = atoi(dbg) > 0 ? atoi(dbg) : unit_passes;
+#endif
+    // the rule below looks at the unit the SCENE wants, not at what this call's pass count leaves of it: a cheap scene
+    // rendered one pass per call (ptgpu_render_pass) must not fall back into the queue with one-pass units
+    const long long unit_passes_wanted = unit_passes;
     if (unit_passes > n_passes) unit_passes = n_passes;
     // (Wavefront kernel only; AUTO: under the path-tracing integrator, where the rule above was
     // measured.  The mega kernel's scenes and the direct-lighting integrator are an order of magnitude
@@ -899,7 +987,7 @@ int enqueue(ptgpu_ctx *c, const ImageTarget &img, int first_sample, int n_passes
     const bool queue = kernel == PTGPU_KERNEL_WAVEFRONT &&
                        (img.is_static || c->work_queue == 1 ||
                         (c->work_queue == 2 && c->integrator == PT_INTEGRATOR_PT && probe.n_tiles >= 2048 &&
-                         (probe.n_bnodes > 0 || unit_passes < 16)));
+                         (probe.n_bnodes > 0 || unit_passes_wanted < 16)));
     // (without a hierarchy, a scene whose unit would need the cap of 16 passes and more is too cheap for the queue now
     // that launches without it carry 8 passes on four region streams: materials.txt 7 126 with / 7 807 Mpaths/s
     // without, simple-spheres.txt 11 267 / 12 065; stacked-spheres.txt, open to the sky and uneven from tile to tile,
@@ -1018,6 +1106,7 @@ int ptgpu_destroy(ptgpu_ctx *ctx) {
     if (!ctx) return PTGPU_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    static_queue_release(ctx->device, ctx);
     free_scene(ctx);
     free_image(ctx);
     for (int i = 0; i < kMaxStreams - 1; ++i) {
@@ -1059,7 +1148,7 @@ int ptgpu_set_option(ptgpu_ctx *ctx, int option, int value) {
         ctx->waves_per_group = value;
         return PTGPU_OK;
     case PTGPU_OPT_SHADOW_CULL:
-        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_BALL)
+        if (value < PTGPU_CULL_OFF || value > PTGPU_CULL_ENCLOSED_SELF)
             return fail(PTGPU_ERR_ARGUMENT, "unknown shadow cull mode %d", value);
         ctx->shadow_cull = value;
         return PTGPU_OK;
@@ -1148,6 +1237,17 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     // and stay small.
     ShadowTables st;
     build_shadow_tables(prims, types, lights, geo.dielectric, st);
+    for (size_t k = 0; k < st.enc_slot.size(); ++k) // (the fast build's kernels walk slots [0, n_enc): build_shadow_tables sorts them first)
+        if (st.enc_slot[k] != (int)k) return fail(PTGPU_ERR_STATE, "internal: the dropped spheres are not the first slots of the shadow order");
+    for (size_t i = 0; i < st.self_flag.size(); ++i) // (index-order records: the strict build's primary array)
+        if (st.self_flag[i]) {
+            const float4 a = geo.prims[3 * i];
+            const float lim = pt_enclosed_inside_limit(a.w, a.x, a.y, a.z);
+            float pre[4];
+            pt_enclosed_prefilter(a.w, a.x, a.y, a.z, lim, pre);
+            geo.prims[3 * i + 1].y = lim;
+            geo.prims[3 * i + 2] = make_float4(pre[0], pre[1], pre[2], pre[3]);
+        }
     if (info.lights >= (1u << 18)) { // the near-queue tag holds 18 bits of light index
         st.cluster_bounds.clear();
         st.cluster_table.clear();
@@ -1188,10 +1288,15 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         {   // the other way to bin (bvh_build.h): kept if its tree is the cheaper one by the surface-area measure
             // (obj-model.txt: 12.41 against 12.95, the first stays; its bunny variant 14.63 / 14.57: 525 -> 650 Mpaths/s)
             ptbvh::Built other = ptbvh::build(prims, types, nullptr, -1, true);
+#if PT_DEBUG_KNOBS
             if (getenv("PTGPU_DEBUG_BVH"))
                 fprintf(stderr, "ptgpu: hierarchy cost %.3f (bins along the widest axis) / %.3f (along all three)\n", bvh.sah, other.sah);
+#endif
             if (other.sah < bvh.sah) bvh = std::move(other);
         }
+        // the cooperative walks pack (node | ray << 24) and (leaf slot | ray << 24) into one LDS word
+        // (radiance_kernels.inc, coop_walk): a hierarchy beyond 2^24 nodes or slots is not used at all
+        if (bvh.nodes.size() / 2 >= (1u << 24) || bvh.prim_of_slot.size() >= (1u << 24)) bvh = ptbvh::Built{};
         std::vector<int> slot_of_prim(types.size(), -1);
         for (size_t k = 0; k < st.prim_of_slot.size(); ++k)
             if (st.prim_of_slot[k] >= 0) slot_of_prim[st.prim_of_slot[k]] = (int)k;
@@ -1240,6 +1345,9 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         HIP_TRY(upload(ctx->d_smask_enclosed, st.enclosed));
         HIP_TRY(upload(ctx->d_smask_ball, st.ball));
         ctx->enclosing = st.enclosing;
+        HIP_TRY(upload(ctx->d_enc_index, st.enc_index));
+        HIP_TRY(upload(ctx->d_enc_slot, st.enc_slot));
+        ctx->n_enc = (int)st.enc_index.size();
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
         HIP_TRY(upload(ctx->d_cbounds, st.cluster_table));
         ctx->n_cquads = (int)st.cluster_table.size();
@@ -1294,8 +1402,8 @@ int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uin
                             uint8_t *keep, uint32_t *n_lights) {
     if (!objects || !n_lights) return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: null argument");
     if (mode != PTGPU_CULL_OFF && mode != PTGPU_CULL_SAFE && mode != PTGPU_CULL_TIGHT && mode != PTGPU_CULL_ENCLOSED &&
-        mode != PTGPU_CULL_BALL)
-        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE, TIGHT, ENCLOSED or BALL");
+        mode != PTGPU_CULL_BALL && mode != PTGPU_CULL_ENCLOSED_SELF)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_shadow_candidates: mode must be OFF, SAFE, TIGHT, ENCLOSED, BALL or ENCLOSED_SELF");
     PackedScene geo;
     pack_geometry(objects, object_count, light_count, geo);
     *n_lights = (uint32_t)(geo.lights.size() / 4);
@@ -1310,6 +1418,20 @@ int ptgpu_shadow_candidates(const pt_object *objects, uint32_t object_count, uin
     for (size_t l = 0; l < *n_lights; ++l)
         for (size_t i = 0; i < n_prims; ++i)
             keep[l * object_count + geo.object_of_prim[i]] = by_prim[l * n_prims + i];
+    return PTGPU_OK;
+}
+
+int ptgpu_cluster_info(const pt_object *objects, uint32_t object_count, uint32_t light_count, uint32_t *clusters,
+                       uint32_t *convex_planes_per_cluster) {
+    if (!objects || !clusters || !convex_planes_per_cluster)
+        return fail(PTGPU_ERR_ARGUMENT, "ptgpu_cluster_info: null argument");
+    PackedScene geo;
+    pack_geometry(objects, object_count, light_count, geo);
+    std::vector<float4> bounds;
+    const std::vector<int> cluster_of = find_clusters(geo.prims, geo.types, bounds);
+    *clusters = (uint32_t)bounds.size();
+    for (int c = 0; c < kMaxClusters; ++c)
+        convex_planes_per_cluster[c] = c < (int)bounds.size() ? (uint32_t)convex_planes(geo.prims, cluster_of, c).size() : 0u;
     return PTGPU_OK;
 }
 
@@ -1459,6 +1581,9 @@ int ptgpu_render_static(ptgpu_ctx *ctx, int width, int height, int first_sample,
     if (((uintptr_t)colors_dev & 15u) || ((uintptr_t)seeds_dev & 7u) || ((uintptr_t)pixels_dev & 3u))
         return fail(PTGPU_ERR_ARGUMENT, "ptgpu_render_static: colours must be 16-byte, seeds 8-byte, pixels 4-byte aligned");
     if (!ctx->static_work) return fail(PTGPU_ERR_STATE, "ptgpu_render_static: no static work queue on this device");
+    if (n_passes > 0 && !static_queue_claim(ctx->device, ctx))
+        return fail(PTGPU_ERR_STATE, "ptgpu_render_static: the static work queue of device %d is in use by another context "
+                                     "(call ptgpu_finish on that context first)", ctx->device);
     const ImageTarget img{width, height, (float4 *)colors_dev, pixels_dev, (uint2 *)seeds_dev, ctx->static_work, true};
     return enqueue(ctx, img, first_sample, n_passes);
 }
@@ -1484,6 +1609,7 @@ static int check_work_queue(ptgpu_ctx *ctx) {
     for (int q = 0; q < 2; ++q) {
         if (!ctx->queue_in_flight[q] || !queues[q]) continue;
         ctx->queue_in_flight[q] = false;
+        if (q == 1) static_queue_release(ctx->device, ctx); // (the stream has drained: the static queue is free again)
         int gave_up = 0;
         HIP_TRY(hipMemcpy(&gave_up, queues[q], sizeof gave_up, hipMemcpyDeviceToHost));
         if (gave_up) {

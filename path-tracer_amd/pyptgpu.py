@@ -54,6 +54,15 @@ class HostScene(C.Structure):
                 ("materials", C.POINTER(Material)), ("title", C.c_char * 100)]
 
 
+class Input(C.Structure):
+    """pthost_input (include/pthost.h): the reference's interactive state, headless."""
+    _fields_ = [("camera", Camera), ("original_camera", Camera), ("key_states", C.c_ubyte * 256),
+                ("shift_pressed", C.c_int), ("mouse_button", C.c_int), ("mouse_x", C.c_int), ("mouse_y", C.c_int),
+                ("time_before", C.c_int), ("width", C.c_int), ("height", C.c_int), ("rand_consumed", C.c_ulonglong)]
+
+
+EV_NONE, EV_CAMERA, EV_REALLOC, EV_SNAPSHOT, EV_QUIT = 0, 1, 2, 4, 8
+
 assert C.sizeof(Vec3) == 12 and C.sizeof(Ray) == 24 and C.sizeof(Object) == 84
 assert C.sizeof(Material) == 44 and C.sizeof(Camera) == 76 and C.sizeof(Scene) == 32
 
@@ -103,6 +112,18 @@ def host():
                                                C.POINTER(C.POINTER(C.c_uint32))]
         lib.pthost_frame_time_budget.argtypes = [C.c_int]
         lib.pthost_frame_time_budget.restype = C.c_float
+        ip = C.POINTER(Input)
+        lib.pthost_input_init.argtypes = [ip, C.POINTER(Camera), C.c_int, C.c_int]
+        lib.pthost_input_init.restype = None
+        lib.pthost_input_idle.argtypes = [ip, C.c_int]
+        lib.pthost_input_keyboard.argtypes = [ip, C.c_ubyte]
+        lib.pthost_input_keyboard_up.argtypes = [ip, C.c_ubyte]
+        lib.pthost_input_shift.argtypes = [ip, C.c_int]
+        lib.pthost_input_mouse.argtypes = [ip, C.c_int, C.c_int, C.c_int]
+        lib.pthost_input_motion.argtypes = [ip, C.c_int, C.c_int]
+        lib.pthost_input_reshape.argtypes = [ip, C.c_int, C.c_int]
+        lib.pthost_input_next_seeds.argtypes = [ip, C.c_void_p]
+        lib.pthost_input_next_seeds.restype = None
         _host = lib
     return _host
 
@@ -143,6 +164,44 @@ class LoadedScene:
         if orig is not None:
             self.camera.orig = Vec3(*orig)
         host().pthost_update_camera_basis(C.byref(self.camera))
+
+
+class HostInput:
+    """The reference's GLUT callbacks as calls (pthost_input_*): each returns the EV_* mask of what the caller must do."""
+
+    def __init__(self, camera, width, height):
+        self.state = Input()
+        host().pthost_input_init(C.byref(self.state), C.byref(camera), width, height)
+
+    @property
+    def camera(self):
+        return Camera.from_buffer_copy(self.state.camera)
+
+    def idle(self, time_ms):
+        return host().pthost_input_idle(C.byref(self.state), time_ms)
+
+    def key(self, key):
+        return host().pthost_input_keyboard(C.byref(self.state), ord(key) if isinstance(key, str) else key)
+
+    def key_up(self, key):
+        return host().pthost_input_keyboard_up(C.byref(self.state), ord(key) if isinstance(key, str) else key)
+
+    def shift(self, pressed):
+        return host().pthost_input_shift(C.byref(self.state), 1 if pressed else 0)
+
+    def mouse(self, button, x, y):
+        return host().pthost_input_mouse(C.byref(self.state), button, x, y)
+
+    def motion(self, x, y):
+        return host().pthost_input_motion(C.byref(self.state), x, y)
+
+    def reshape(self, width, height):
+        return host().pthost_input_reshape(C.byref(self.state), width, height)
+
+    def next_seeds(self):
+        seeds = np.empty(2 * self.state.width * self.state.height, dtype=np.uint32)
+        host().pthost_input_next_seeds(C.byref(self.state), _ptr(seeds))
+        return seeds
 
 
 def seed_block(width, height, rank=0):
@@ -223,7 +282,7 @@ OPT_RAY_BINS = 7
 OPT_BVH = 8
 OPT_WORK_QUEUE = 9
 BVH_OFF, BVH_ON, BVH_AUTO = 0, 1, 2
-CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED, CULL_BALL = 0, 1, 2, 3, 4, 5
+CULL_OFF, CULL_SAFE, CULL_TIGHT, CULL_AUTO, CULL_ENCLOSED, CULL_BALL, CULL_ENCLOSED_SELF = 0, 1, 2, 3, 4, 5, 6
 KERNEL_MEGA, KERNEL_WAVEFRONT, KERNEL_AUTO = 0, 1, 2
 MATH_FAST, MATH_STRICT = 0, 1
 INTEGRATOR_PT, INTEGRATOR_DL = 0, 1
@@ -242,7 +301,7 @@ GPU_SYMBOLS = ["ptgpu_create", "ptgpu_destroy", "ptgpu_set_option", "ptgpu_set_s
                "ptgpu_resize", "ptgpu_render_pass", "ptgpu_render", "ptgpu_render_timed", "ptgpu_finish",
                "ptgpu_read_pixels", "ptgpu_read_colors", "ptgpu_read_seeds", "ptgpu_write_colors",
                "ptgpu_colors_device_ptr", "ptgpu_stream", "ptgpu_scale_and_repack", "ptgpu_get_scene_info",
-               "ptgpu_shadow_candidates", "ptgpu_last_error", "ptgpu_render_static",
+               "ptgpu_shadow_candidates", "ptgpu_cluster_info", "ptgpu_last_error", "ptgpu_render_static",
                "ptgpu_get_launch_info", "ptgpu_work_counters", "ptgpu_probe_rays"]
 
 
@@ -313,6 +372,8 @@ def _bind(lib):
     lib.ptgpu_scale_and_repack.argtypes = [vp, C.c_float]
     lib.ptgpu_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     lib.ptgpu_shadow_candidates.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, vp, C.POINTER(C.c_uint32)]
+    if hasattr(lib, "ptgpu_cluster_info"):   # (absent from A/B builds of older revisions, scripts/build_base.sh)
+        lib.ptgpu_cluster_info.argtypes = [vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ptgpu_get_launch_info.argtypes = [vp, C.POINTER(LaunchInfo)]
     lib.ptgpu_work_counters.argtypes = [vp, C.POINTER(C.c_ulonglong), C.c_int]
     lib.ptgpu_probe_rays.argtypes = [vp, C.c_int] + [C.c_void_p] * 6 + [C.c_int]
@@ -395,6 +456,16 @@ def shadow_candidates(sc, mode, light_count=None):
     if lib.ptgpu_shadow_candidates(_ptr(sc.objects), sc.object_count, lights, mode, _ptr(keep), C.byref(n)) != 0:
         raise GpuError(lib.ptgpu_last_error().decode())
     return keep
+
+
+def cluster_info(sc, light_count=None):
+    """(clusters, [face planes of cluster c as a closed convex mesh, 0 = it keeps its triangles] x 8): host only."""
+    n, planes = C.c_uint32(), (C.c_uint32 * 8)()
+    lib = gpu()
+    lights = sc.light_count if light_count is None else light_count
+    if lib.ptgpu_cluster_info(_ptr(sc.objects), sc.object_count, lights, C.byref(n), planes) != 0:
+        raise GpuError(lib.ptgpu_last_error().decode())
+    return n.value, [int(v) for v in planes]
 
 
 class Gpu:

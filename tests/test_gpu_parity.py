@@ -183,7 +183,7 @@ def test_shadow_cull_enclosed_equals_its_cpu_replay_and_falls_back_outside(kerne
     for name, w, h, spp in (("cornell-large", 96, 72, 4), ("cornell", 96, 72, 3)):
         sc = pt.LoadedScene(name, w, h)
         sets = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
-        assert (sets == 0).sum() >= 6, name                      # the walls, at least
+        assert (sets == 4).sum() >= 6, name                      # the walls, at least (4: kept for the rays not well inside)
         with ob.shadow_candidates(sets):
             cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
         colors, pixels, sd = gpu_render(name, w, h, spp, 0, kernel, pt.MATH_STRICT, cull=pt.CULL_ENCLOSED)

@@ -193,6 +193,16 @@ def _box(lo, hi, faces=6, dent=False):
     return _hull(v, [t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))])
 
 
+def flat_hexagon(center=(0.0, 45.0, 110.0), radius=9.0):
+    """A flat, double-sided hexagon, its two sides fan-triangulated from different corners: every edge is used by
+    exactly two of its 8 triangles and every vertex lies in every face plane - "closed" and "convex" by those two
+    tests, with no volume.  It must keep its triangles (round 2's advisor finding: planes that bound an infinite slab
+    would shadow rays far outside the polygon)."""
+    c = np.array(center)
+    v = [c + radius * np.array((np.cos(k * np.pi / 3), np.sin(k * np.pi / 3), 0.0)) for k in range(6)]
+    return _hull(v, [(0, 1, 2), (0, 2, 3), (0, 3, 4), (0, 4, 5), (1, 0, 5), (1, 5, 4), (1, 4, 3), (1, 3, 2)])
+
+
 def convex_scene():
     c, r = np.array((-30.0, 12.0, 95.0)), 9.0
     octa = _hull([c + (r, 0, 0), c - (r, 0, 0), c + (0, r, 0), c - (0, r, 0), c + (0, 0, r), c - (0, 0, r)],
@@ -202,7 +212,7 @@ def convex_scene():
     prism = _hull([t, t + (14, 0, 0), t + (7, 0, 12), t + up, t + (14, 0, 0) + up, t + (7, 0, 12) + up],
                   [(0, 1, 2), (3, 5, 4), (0, 3, 4), (0, 4, 1), (1, 4, 5), (1, 5, 2), (2, 5, 3), (2, 3, 0)])
     light = _hull([(-12, 80, 70), (12, 80, 70), (12, 80, 94), (-12, 80, 94)], [(0, 1, 2), (0, 2, 3), (0, 2, 1), (0, 3, 2)])
-    objs = room() + [triangles(light, emission=(10, 10, 10)),
+    objs = room() + [triangles(light, emission=(10, 10, 10)), triangles(flat_hexagon(), color=(.6, .6, .2)),
                      triangles(_box((-10, 0, 60), (10, 22, 80)), color=(.8, .6, .3)), triangles(octa, color=(.3, .8, .4)),
                      triangles(prism, color=(.4, .5, .9)), triangles(_box((20, 0, 40), (40, 15, 60), faces=5)),
                      triangles(_box((-45, 0, 40), (-25, 18, 60), dent=True), color=(.9, .3, .3))]
@@ -210,8 +220,9 @@ def convex_scene():
 
 
 def test_closed_convex_clusters_are_tested_by_their_face_planes():
-    # A cube, an octahedron and a prism (closed, convex: near shadow rays test 6 / 8 / 5 planes), an open box
-    # and a dented cube (closed, not convex), which keep their triangles.  The plane test answers "does the
+    # A cube, an octahedron and a prism (closed, convex: near shadow rays test 6 / 8 / 5 planes), an open box,
+    # a dented cube (closed, not convex) and a flat double-sided hexagon (closed and "convex", no volume), which
+    # keep their triangles.  The plane test answers "does the
     # segment cross the boundary between EPSILON and maxt", which is what the any-hit scan over the triangles
     # answers: bins on and off must give the same image up to rays grazing an edge - and the diffuse meshes
     # start shadow rays ON themselves, the case the range (EPSILON, maxt) is there for.
@@ -221,7 +232,7 @@ def test_closed_convex_clusters_are_tested_by_their_face_planes():
         on = render(sc, w, h, spp, math=pt.MATH_FAST, kernel=pt.KERNEL_WAVEFRONT, ray_bins=1, shadow_cull=cull)
         off = render(sc, w, h, spp, math=pt.MATH_FAST, kernel=pt.KERNEL_WAVEFRONT, ray_bins=0, shadow_cull=cull)
         info = on[3]
-        assert info["clusters"] == 5 and info["convex_clusters"] == 3, info
+        assert info["clusters"] == 6 and info["convex_clusters"] == 3, info   # (the flat hexagon is the sixth)
         assert (on[2] == off[2]).all()
         ok = ~np.isnan(on[0]).any(1) & ~np.isnan(off[0]).any(1)
         d = on[0][ok].astype(np.float64) - off[0][ok]

@@ -7,9 +7,14 @@ What is proven here on the CPU
   * TIGHT is a subset of SAFE, culls only primitives that lie in the closed half-space behind the
     light's plane, and moves the image by less than the calibrated FP floor (it can differ only for
     rays that graze the light's own plane, where the contribution's cosine factor is ~0);
-  * ENCLOSED is TIGHT minus the opaque spheres a triangle light lies wholly inside, moves the image
-    by about 1e-4 of its radiance (upstream's float "acne" on the sphere a shadow ray starts from),
-    and never drops a dielectric sphere or a sphere the light pokes out of.
+  * ENCLOSED is TIGHT minus the opaque spheres a light lies wholly inside - for the rays that start
+    well inside those spheres (keep value 4: every path vertex is checked, upstream's paths do leave
+    their room through its corners) - never drops a dielectric sphere or a sphere the light pokes out
+    of, and moves the image by 1e-6 .. 1e-5 of its radiance, no sign (upstream's float "acne" on the
+    sphere a shadow ray starts from); round 2's version assumed the paths stay inside and was
+    brighter than upstream by 1.1e-4, one-signed;
+  * ENCLOSED_SELF (keep value 3: also the rays that start ON a dropped sphere test it) is TIGHT, bit
+    for bit.
 """
 import numpy as np
 import pytest
@@ -122,8 +127,12 @@ def test_enclosed_drops_only_opaque_spheres_around_the_light():
     o, real, lights = geometry(sc)
     tight = pt.shadow_candidates(sc, pt.CULL_TIGHT)
     enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
-    assert (enc <= tight).all()
-    changed = np.argwhere(tight != enc)
+    # 4: a dropped sphere stays for the rays that start not well inside it - whatever the light, also where TIGHT
+    # itself culls the sphere (the kernels keep one bit per vertex and sphere, not per light; testing more than a
+    # set asks for is upstream's own scan)
+    assert set(np.unique(enc)) <= {0, 1, 4} and ((enc == 1) <= (tight == 1)).all()
+    assert (o["type"][np.argwhere(enc == 4)[:, 1]] == 0).all()
+    changed = np.argwhere((tight == 1) & (enc != 1))
     assert len(changed) > 500                                   # ~5 of the 6 wall spheres for each of 123 lights
     for l, i in changed:
         li = lights[l]
@@ -135,7 +144,7 @@ def test_enclosed_drops_only_opaque_spheres_around_the_light():
     # the lights that reach below it keep the floor sphere, and nothing else is kept of the walls
     walls = np.nonzero((o["type"] == 0) & (o["radius"] >= 1000))[0]
     floor = [i for i in walls if o["center"][i][1] > 9000][0]
-    kept = enc[:, walls].sum(0)
+    kept = (enc[:, walls] == 1).sum(0)
     assert kept[list(walls).index(floor)] > 30 and kept.sum() == kept[list(walls).index(floor)]
     # a glass wall encloses nothing: paths leave through it
     sc.objects["material_id"][walls] = 2
@@ -143,22 +152,76 @@ def test_enclosed_drops_only_opaque_spheres_around_the_light():
     assert (glass == tight).all()
 
 
-def test_enclosed_replay_moves_cornell_by_its_acne_only():
+@pytest.mark.parametrize("name", ["cornell", "cornell-large", "cornell-original"])
+def test_enclosed_family_replay_against_tight(name):
+    # ENCLOSED_SELF answers every shadow ray as TIGHT does: the same image, bit for bit.  ENCLOSED leaves out the
+    # sphere a ray STARTS on: grazing rays whose weight is ~0 - some pixels move, the mean does not (<= 2e-5 of the
+    # radiance; round 2's ENCLOSED, which assumed that paths never leave the spheres, was +1.1e-4 .. +1.3e-4 here).
+    # The premise that fails upstream is visible in the oracle's own log: shadow rays that start OUTSIDE a wall.
     w, h, spp = 96, 72, 6
-    sc = pt.LoadedScene("cornell", w, h)
+    sc = pt.LoadedScene(name, w, h)
     seeds = pt.seed_block(w, h)
-    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_TIGHT)):
-        tight = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
-    with ob.shadow_candidates(pt.shadow_candidates(sc, pt.CULL_ENCLOSED)):
-        enc = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
-    assert (tight.seeds == enc.seeds).all()                     # draws never depend on a shadow test
+    res = {}
+    for mode in (pt.CULL_TIGHT, pt.CULL_ENCLOSED, pt.CULL_ENCLOSED_SELF):
+        with ob.shadow_candidates(pt.shadow_candidates(sc, mode)):
+            res[mode] = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+    tight, enc, own = res[pt.CULL_TIGHT], res[pt.CULL_ENCLOSED], res[pt.CULL_ENCLOSED_SELF]
+    assert (tight.seeds == enc.seeds).all() and (tight.seeds == own.seeds).all()   # draws never depend on a shadow test
+    assert same_bits(own.colors, tight.colors) and (own.pixels == tight.pixels).all()
     ok = ~(np.isnan(tight.colors).any(1) | np.isnan(enc.colors).any(1))
     d = enc.colors[ok].astype(np.float64) - tight.colors[ok]
     mean = float(tight.colors[ok].mean())
-    print(f"ENCLOSED vs TIGHT on the CPU: {(np.abs(d).max(1) > 0).mean():.3f} of the pixels differ, "
+    print(f"{name}: ENCLOSED vs TIGHT on the CPU: {(np.abs(d).max(1) > 0).mean():.3f} of the pixels differ, "
           f"mean {d.mean() / mean:+.2e}, rmse {np.sqrt((d ** 2).mean()) / mean:.2e} of the radiance")
     assert (d >= -1e-6).all()                                   # only occlusions are lost: nothing gets darker
-    assert 0 <= d.mean() <= 1e-3 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean
+    assert 0 <= d.mean() <= 2e-5 * mean and np.sqrt((d ** 2).mean()) <= 1e-2 * mean
+
+
+def test_paths_leave_the_room_through_its_corners_and_enclosed_keeps_their_walls():
+    # The finding behind round 3's ENCLOSED: with the sets of a rule that assumes "a path never leaves an opaque
+    # sphere" (4 -> 0: round 2's ENCLOSED), the oracle's mismatch log shows shadow rays that the full scan finds
+    # occluded by a wall the origin is OUTSIDE of (a bounce ray that starts within EPSILON of a second wall passes
+    # through it, geomfunc.h:36) - every light of such a vertex, and that is the one-signed bias.  With the
+    # per-vertex check (4) the only mismatches left are rays occluded by the sphere they start on.
+    import ctypes as C
+    lib = ob.oracle()
+    lib.oracle_set_mismatch_log.argtypes = [C.c_void_p, C.c_int]
+    lib.oracle_set_mismatch_log.restype = None
+    w, h, spp = 96, 72, 2
+    sc = pt.LoadedScene("cornell", w, h)
+    o = sc.objects
+    seeds = pt.seed_block(w, h)
+    tight = pt.shadow_candidates(sc, pt.CULL_TIGHT)
+    enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
+    naive = np.where(enc == 4, 0, enc).astype(np.uint8)
+
+    def mismatches(keep):
+        log = np.zeros((100000, 12), dtype=np.float32)
+        lib.oracle_set_mismatch_log(log.ctypes.data, len(log))
+        try:
+            with ob.shadow_candidates(keep):
+                ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=1)
+            n = lib.oracle_mismatch_count()
+        finally:
+            lib.oracle_set_mismatch_log(None, 0)
+        rec = log[:n]
+        spheres = o["type"][rec[:, 9].astype(int)] == 0        # the full scan's occluder is a sphere (else: TIGHT's class)
+        return rec[spheres]
+
+    base = len(mismatches(tight))                                # (TIGHT never drops a sphere: nothing to find)
+    assert base == 0
+    lost = mismatches(naive)
+    own = lost[:, 8] == lost[:, 9]
+    outside = []
+    for r in lost[~own]:
+        c, rad = o["center"][int(r[9])].astype(np.float64), float(o["radius"][int(r[9])])
+        outside.append(np.linalg.norm(r[:3].astype(np.float64) - c) - rad)
+    outside = np.array(outside)
+    print(f"assumed-inside sets: {len(lost)} shadow rays lose a sphere occluder; {own.sum()} start on it, "
+          f"{(~own).sum()} elsewhere, of which {(outside > 0).sum()} start outside that sphere (median {np.median(outside):+.3f})")
+    assert (~own).sum() > 500 and (outside > -0.04).all() and (outside > 0).mean() > 0.9
+    kept = mismatches(enc)
+    assert len(kept) > 0 and (kept[:, 8] == kept[:, 9]).all()    # what is left: rays occluded by the sphere they stand on
 
 
 def test_ball_marks_the_enclosing_spheres_a_light_reaches_out_of():
@@ -166,7 +229,7 @@ def test_ball_marks_the_enclosing_spheres_a_light_reaches_out_of():
     o, real, lights = geometry(sc)
     enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
     ball = pt.shadow_candidates(sc, pt.CULL_BALL)
-    assert ((ball != 0) == (enc != 0)).all()                    # the same pairs, some tested another way
+    assert ((ball != 0) == (enc != 0)).all() and ((ball == 4) == (enc == 4)).all()     # the same pairs, some tested another way
     marked = np.argwhere(ball == 2)
     walls = np.nonzero((o["type"] == 0) & (o["radius"] >= 1000))[0]
     floor = [i for i in walls if o["center"][i][1] > 9000][0]
@@ -183,7 +246,7 @@ def test_ball_marks_the_enclosing_spheres_a_light_reaches_out_of():
         b2, e2 = pt.shadow_candidates(s2, pt.CULL_BALL), pt.shadow_candidates(s2, pt.CULL_ENCLOSED)
         o2 = s2.objects
         for l, i in np.argwhere(b2 == 2):
-            assert o2["type"][i] == 0 and o2["material_id"][i] != 2 and (e2[:, i] == 0).any()
+            assert o2["type"][i] == 0 and o2["material_id"][i] != 2 and (e2[:, i] == 4).any()
         if name == "complex":
             assert (b2 == e2).all()
     sc.objects["material_id"][walls] = 2                        # glass walls enclose nothing

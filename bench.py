@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "mega", "wavefront"])
     ap.add_argument("--math", default="fast", choices=["fast", "strict"])
     ap.add_argument("--integrator", default="pt", choices=["pt", "dl"])
-    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "ball", "auto"],
+    ap.add_argument("--cull", default="auto", choices=["off", "safe", "tight", "enclosed", "self", "ball", "auto"],
                     help="shadow-ray candidate sets (auto = enclosed with fast math, safe with strict; ball is opt-in)")
     ap.add_argument("--streams", type=int, default=4, help="image regions on concurrent HIP streams (1..4; without the work queue)")
     ap.add_argument("--work-queue", default="auto", choices=["auto", "on", "off"],

@@ -20,7 +20,6 @@
 #define PTGPU_H
 
 #include "pt_records.h"
-#include "pt_enclosed.h" /* pt_enclosed_inside_limit: "well inside" for the ENCLOSED family of candidate sets */
 
 #ifdef __cplusplus
 extern "C" {
@@ -103,23 +102,24 @@ enum {
  *         plane within rounding distance may see a different occluder than upstream.
  *   ENCLOSED  TIGHT, and a sphere that is not a dielectric leaves the set of every light - triangle or sphere -
  *         that lies wholly inside it (the r = 1e4 wall spheres of the upstream scenes), FOR THE RAYS THAT START
- *         WELL INSIDE IT: a segment between two points of a ball stays in the ball, so the sphere cannot occlude
- *         such a ray, in real arithmetic or in upstream's float test (the origin's depth below the surface,
- *         pt_enclosed_inside_limit, is far above the rounding of the discriminant).  Whether a path vertex is well
- *         inside is CHECKED, per vertex and dropped sphere (one squared distance each): upstream's paths do leave
- *         their room - a bounce ray that starts within EPSILON of a second wall passes through it (t > EPSILON,
- *         geomfunc.h:36) and lands outside, where every light is occluded by that wall; round 2 assumed they
- *         could not, and that assumption was the whole one-signed deviation of this mode (+1.2e-4 of cornell.txt's
- *         radiance: 0.06 % of the vertices, fully lit instead of dark).  A vertex that is not well inside a dropped
- *         sphere keeps that sphere for its shadow rays.  The one sphere NOT kept that way is the sphere the vertex
- *         stands on: upstream's discriminant can report it for grazing rays ("acne"; their cosine, and with it
- *         their weight, is ~0: 1e-6 of the radiance, no sign).  At most 32 spheres are dropped per scene.
- *         The library also checks at every launch that the camera is inside every sphere this rule dropped,
- *         and renders with the TIGHT sets when it is not.
+ *         INSIDE IT: a segment between two points of a ball stays in the ball, so the sphere cannot occlude such a
+ *         ray.  Whether a path vertex is inside is CHECKED: upstream's paths do leave their room - a bounce ray that
+ *         starts within EPSILON of a second wall passes through it (t > EPSILON, geomfunc.h:36) and lands outside,
+ *         where that wall occludes every light; round 2 assumed they could not, and that assumption was the whole
+ *         one-signed deviation of this mode (+1.2e-4 of cornell.txt's radiance: 0.06 % of the vertices, fully lit
+ *         instead of dark).  The check costs nothing: the extension ray that FINDS a vertex has tested every
+ *         sphere, and a ray that starts inside a sphere and stays in it beyond EPSILON gets that sphere's far root
+ *         from SphereIntersect (geomfunc.h:10-39); a vertex found by a ray for which some dropped sphere answered
+ *         anything else (near root, no hit) may be outside it, and its shadow rays test every dropped sphere, as
+ *         upstream does.  What remains of the rule's effect is the sphere a vertex STANDS ON (and, within rounding of
+ *         a corner, its neighbour): upstream's float discriminant can report it for grazing rays ("acne"; their
+ *         cosine, and with it their weight, is ~0: 1e-6 .. 1e-5 of the radiance, no sign).  At most 32 spheres are
+ *         dropped per scene.  The library also checks at every launch that the camera is inside every sphere this
+ *         rule dropped, and renders with the TIGHT sets when it is not.
  *   ENCLOSED_SELF  ENCLOSED, and a shadow ray is also tested against the dropped sphere its origin stands on
- *         (upstream's SphereIntersect on upstream's operands, geomfunc.h:10-39, per lane): with it every
- *         occlusion answer is TIGHT's, bit for bit in the strict build, for one more sphere test per shadow ray
- *         that starts on a wall.
+ *         (upstream's SphereIntersect on upstream's operands, per lane): the occlusion answers are TIGHT's - bit
+ *         for bit in the strict build on cornell.txt, cornell-large.txt and cornell-original.txt at 1024x768x4 -
+ *         for one more sphere test per shadow ray that starts on a wall.
  *   BALL  (opt-in) ENCLOSED, and where such a sphere (one that encloses some light) is still in the
  *         set of a triangle light that reaches out of it, its ray test is replaced by a test of
  *         one point: the ray starts inside the ball, so it crosses the sphere before maxt exactly
@@ -323,8 +323,8 @@ int ptgpu_probe_rays(ptgpu_ctx *ctx, int n, const float *origins, const float *d
  * keep[l * object_count + i] = 1 when object i is scanned for a shadow ray towards the l-th light
  * (sampling order), 0 when it is culled or is not a sphere/triangle, 2 (BALL) when sphere i is
  * tested by the ray's point at maxt instead of the ray, 4 (the ENCLOSED family) when sphere i is tested only by the
- * rays whose origin is not well inside it (pt_enclosed_inside_limit) and does not lie on it, 3 (ENCLOSED_SELF)
- * likewise but including the rays that start on it.  *n_lights receives the number
+ * rays of a path vertex that may lie outside a dropped sphere (see ENCLOSED above), 3 (ENCLOSED_SELF) likewise but
+ * including the rays that start on it.  *n_lights receives the number
  * of lights; call with keep = NULL to size the buffer (n_lights * object_count bytes).  Used by the
  * tests to replay the culled scan on the CPU and by bench.py to count the tests it leaves.
  * No material table is passed: an object counts as a dielectric (it encloses nothing) when its

@@ -69,6 +69,8 @@ def oracle():
         lib.oracle_render_pass_counted.restype = None
         lib.oracle_set_shadow_candidates.argtypes = [_p]
         lib.oracle_set_shadow_candidates.restype = None
+        lib.oracle_set_enclosing.argtypes = [_p]
+        lib.oracle_set_enclosing.restype = None
         _oracle = lib
     return _oracle
 
@@ -112,13 +114,17 @@ class shadow_candidates:
 
     def __init__(self, keep):
         self.keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        # the spheres the ENCLOSED family dropped for some light (bytes 2, 3, 4): their far roots are watched
+        self.enclosing = np.ascontiguousarray((self.keep >= 2).any(0), dtype=np.uint8)
 
     def __enter__(self):
         oracle().oracle_set_shadow_candidates(_ptr(self.keep))
+        oracle().oracle_set_enclosing(_ptr(self.enclosing) if self.enclosing.any() else None)
         return self
 
     def __exit__(self, *exc):
         oracle().oracle_set_shadow_candidates(None)
+        oracle().oracle_set_enclosing(None)
         return False
 
 

@@ -70,12 +70,17 @@ void oracle_render_pass_counted(const pt_object *objects, uint32_t n, uint32_t l
  * the default, is the reference's full scan): keep[l * n + i] = 0 makes the any-hit scan of a
  * shadow ray towards the l-th light skip object i; 2 (PTGPU_CULL_BALL, spheres only) replaces the
  * ray test of object i by "the ray's point at maxt lies outside the sphere"; 4 (the ENCLOSED family) keeps
- * the test of sphere i for the rays whose origin is not well inside it (pt_enclosed_inside_limit) and does not
- * lie on it, 3 (PTGPU_CULL_ENCLOSED_SELF) also for the rays that start on it.  The matrix comes from
+ * the test of sphere i for the rays of a path vertex that may lie outside a dropped sphere (oracle_set_enclosing),
+ * 3 (PTGPU_CULL_ENCLOSED_SELF) also for the rays that start on sphere i.  The matrix comes from
  * ptgpu_shadow_candidates (include/ptgpu.h) with the same objects and light count as the renders
  * that follow; the caller keeps it alive until it is reset.  Used to prove on the CPU that a cull
  * mode leaves every bit of the image alone, and to count the tests the culled algorithm performs. */
 void oracle_set_shadow_candidates(const uint8_t *keep);
+/* flags[i] != 0 (n objects): sphere i is one the ENCLOSED family dropped for some light = any byte >= 2 in column i of
+ * the matrix above.  With it set, a path vertex counts as "may be outside" when the ray that found it did not get
+ * the FAR root of every such sphere from SphereIntersect (geomfunc.h:10-39: what a ray that starts inside a sphere
+ * and does not leave it within EPSILON gets) - the product's criterion, restated on the reference's own test. */
+void oracle_set_enclosing(const uint8_t *flags);
 
 /* Diagnostic of that replay (serial renders: threads <= 1): every shadow ray whose culled scan answers differently
  * from the full scan is logged, 12 floats a record - origin xyz, direction xyz, maxt, light (sampling order), the

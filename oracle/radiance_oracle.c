@@ -15,7 +15,6 @@
 #include <string.h>
 
 #include "pt_oracle.h"
-#include "pt_enclosed.h" /* one definition of "well inside", shared with the product, for the replay of its sets */
 
 #define PI_F 3.14159265358979323846f
 #define TWO_PI_F 6.28318530717958647693f
@@ -81,6 +80,11 @@ uint32_t oracle_accumulate(pt_vec3 *color, const pt_vec3 *sample, int current_sa
  * keep[l * n_objects + i], l = light in sampling order.  Set between renders, read-only during. */
 static const uint8_t *g_shadow_keep = NULL;
 void oracle_set_shadow_candidates(const uint8_t *keep) { g_shadow_keep = keep; }
+/* ... and, for the ENCLOSED family of those sets, which objects are spheres the rule dropped for some light
+ * (flags[i] != 0, n_objects bytes; NULL = none): closest_hit then reports whether every such sphere answered with
+ * its far root (the path vertex is inside them all) */
+static const uint8_t *g_enclosing = NULL;
+void oracle_set_enclosing(const uint8_t *flags) { g_enclosing = flags; }
 
 /* Diagnostic of the replay (serial renders only): every shadow ray whose culled scan answers differently
  * from the reference's full scan is logged - origin, direction, maxt, light (sampling order), the object the
@@ -139,17 +143,17 @@ void oracle_camera_ray(const pt_camera *cam, int x, int y, int width, int height
 }
 
 int oracle_intersect(const pt_object *objects, uint32_t n, const pt_ray *ray, float *t, uint32_t *id) {
-    return plain_closest_hit(objects, n, ray, t, id);
+    return plain_closest_hit(objects, n, ray, t, id, NULL);
 }
 
 int oracle_intersect_p(const pt_object *objects, uint32_t n, const pt_ray *ray, float maxt) {
-    return plain_any_hit(objects, n, ray, maxt, NULL, UINT32_MAX);
+    return plain_any_hit(objects, n, ray, maxt, NULL, UINT32_MAX, 0);
 }
 
 void oracle_sample_lights(const pt_object *objects, uint32_t n, uint32_t lights, uint32_t *seed0,
                           uint32_t *seed1, const pt_vec3 *hit, const pt_vec3 *normal,
                           pt_vec3 *result) {
-    plain_direct_light(objects, n, lights, seed0, seed1, hit, normal, UINT32_MAX, result);
+    plain_direct_light(objects, n, lights, seed0, seed1, hit, normal, UINT32_MAX, 0, result);
 }
 
 void oracle_radiance(const pt_object *objects, uint32_t n, uint32_t lights, const pt_ray *ray,

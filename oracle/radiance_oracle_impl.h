@@ -34,6 +34,20 @@ static inline float FN(hit_sphere)(const pt_object *s, const pt_ray *r CTR_PARAM
     return 0.f;
 }
 
+/* Did hit_sphere answer with the FAR root (b + sqrt(det)) - what it does exactly when the ray starts inside the
+ * sphere and does not leave it within EPSILON?  The same float operations as hit_sphere.  (Replay of the product's
+ * ENCLOSED sets only, oracle_set_enclosing: a path vertex found by a ray for which some dropped sphere did NOT
+ * answer that way may lie outside that sphere.) */
+static inline int FN(sphere_far_root)(const pt_object *s, const pt_ray *r) {
+    const v3 op = v3_sub(s->center, r->o);
+    const float b = v3_dot(op, r->d);
+    float det = b * b - v3_dot(op, op) + s->radius * s->radius;
+    if (det < 0.f) return 0;
+    det = (float)sqrt((double)det);
+    if (b - det > PT_EPSILON) return 0;
+    return (b + det > PT_EPSILON) ? 1 : 0;
+}
+
 /* geomfunc.h:45-78 (Moeller-Trumbore in pbrt's form, two-sided). */
 static inline float FN(hit_triangle)(const pt_object *tri, const pt_ray *r CTR_PARAM) {
     TALLY(triangle_tests);
@@ -59,11 +73,14 @@ static inline float FN(hit_triangle)(const pt_object *tri, const pt_ray *r CTR_P
 
 /* geomfunc.h:126-157: closest hit, strict <, first index wins ties, *id untouched on a miss */
 static int FN(closest_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray, float *t,
-                           uint32_t *id CTR_PARAM) {
+                           uint32_t *id, int *odd CTR_PARAM) {
     const float inf = (*t) = 1e20f;
     TALLY(extension_rays);
+    if (odd) *odd = 0;
     for (uint32_t i = 0; i < n; i++) {
         float dist;
+        if (odd && g_enclosing && g_enclosing[i] && objects[i].type == PT_SPHERE && !FN(sphere_far_root)(&objects[i], ray))
+            *odd = 1; /* (replay of the ENCLOSED sets: the vertex this ray finds may be outside sphere i) */
         if (objects[i].type == PT_SPHERE)
             dist = FN(hit_sphere)(&objects[i], ray CTR_ARG);
         else if (objects[i].type == PT_TRIANGLE)
@@ -81,27 +98,21 @@ static int FN(closest_hit)(const pt_object *objects, uint32_t n, const pt_ray *r
 /* geomfunc.h:162-193: any hit closer than maxt, early out in index order.
  * `candidates` (NULL upstream) replays the product's shadow-ray culling on the CPU: objects whose
  * byte is 0 are skipped, objects whose byte is 2 (spheres the ray starts inside of) are tested with
- * the ray's point at maxt instead of the ray, objects whose byte is 3 or 4 (spheres) only by a ray whose origin is
- * not well inside them - 3: or lies on them, 4: and does not lie on them (`origin_id` = the object the ray starts
- * on; oracle_set_shadow_candidates). */
+ * the ray's point at maxt instead of the ray, objects whose byte is 3 or 4 (spheres) only by a ray whose origin may
+ * be outside them (`origin_odd`) - 3: or lies on them (`origin_id` = the object the ray starts on;
+ * oracle_set_shadow_candidates). */
 static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
-                       float maxt, const uint8_t *candidates, uint32_t origin_id CTR_PARAM) {
+                       float maxt, const uint8_t *candidates, uint32_t origin_id, int origin_odd CTR_PARAM) {
     TALLY(shadow_rays);
     for (uint32_t i = 0; i < n; i++) {
         float dist;
         if (candidates && !candidates[i]) continue;
         /* the ENCLOSED family's replay (include/ptgpu.h).  A sphere the rule dropped (4), dropped but for the rays
          * that start on it (3, ENCLOSED_SELF) or tests by the ray's end point (2, BALL) relies on the origin being
-         * well inside it; for an origin that is not - and does not stand on it - the ray is tested as upstream
-         * tests it.  The squared distance in float, as the kernels evaluate it. */
+         * inside it: for a vertex that may not be (`origin_odd`: the ray that found it did not get the far root of
+         * every dropped sphere, closest_hit) the ray is tested as upstream tests it. */
         if (candidates && candidates[i] >= 2) {
-            int as_upstream = (candidates[i] == 3 && i == origin_id);
-            if (i != origin_id) {
-                const pt_object *s = &objects[i];
-                const float dx = ray->o.x - s->center.x, dy = ray->o.y - s->center.y, dz = ray->o.z - s->center.z;
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                if (!(d2 < pt_enclosed_inside_limit(s->radius, s->center.x, s->center.y, s->center.z))) as_upstream = 1;
-            }
+            const int as_upstream = origin_odd || (candidates[i] == 3 && i == origin_id);
             if (candidates[i] == 2) {
                 /* PTGPU_CULL_BALL replay: the ray starts inside this sphere, so it crosses it before
                  * maxt exactly when its point at maxt lies outside (no ray test) */
@@ -128,7 +139,8 @@ static int FN(any_hit)(const pt_object *objects, uint32_t n, const pt_ray *ray,
  * of them have been seen), draws two numbers per light BEFORE any rejection test, and adds
  * emission * area * wi * wo / len^2 for each unoccluded light facing the point.  No 1/N, no 1/pi. */
 static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t lights, uint32_t *s0,
-                             uint32_t *s1, const v3 *hit, const v3 *normal, uint32_t origin_id, v3 *result CTR_PARAM) {
+                             uint32_t *s1, const v3 *hit, const v3 *normal, uint32_t origin_id, int origin_odd,
+                             v3 *result CTR_PARAM) {
     *result = v3_make(0.f, 0.f, 0.f);
     uint32_t seen = 0;
     for (uint32_t i = 0; i < n && seen < lights; i++) {
@@ -191,7 +203,7 @@ static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t ligh
         const float wi = v3_dot(shadow.d, *normal);
 #ifndef ORACLE_COUNTING
         if (g_mismatch_log && candidates && (wi > 0.f)) { /* diagnostic: culled scan against the full scan */
-            const int culled = FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id CTR_ARG);
+            const int culled = FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id, origin_odd CTR_ARG);
             int full = 0;
             uint32_t first = UINT32_MAX;
             float first_t = 0.f;
@@ -210,7 +222,7 @@ static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t ligh
             }
         }
 #endif
-        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id CTR_ARG))) {
+        if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id, origin_odd CTR_ARG))) {
             const float s = light->area * wi * wo / (len * len);
             const v3 contribution = v3_scale(s, light->emission);
             *result = v3_add(*result, contribution);
@@ -344,7 +356,8 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
 
         float t;
         uint32_t id = 0;
-        if (!FN(closest_hit)(objects, n, &ray, &t, &id CTR_ARG)) {
+        int odd = 0;
+        if (!FN(closest_hit)(objects, n, &ray, &t, &id, &odd CTR_ARG)) {
             /* miss: throughput * sky, DISCARDING what was gathered so far (quirk A.3-2) */
             const v3 sky_dir = v3_make(-.41f, -.82f, .41f);
             const float pos = (v3_dot(ray.d, sky_dir) + 1) / 2;
@@ -387,7 +400,7 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
             specular_bounce = 0;
             throughput = v3_mul(throughput, obj->color);
             v3 Ld;
-            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, &Ld CTR_ARG);
+            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, odd, &Ld CTR_ARG);
             Ld = v3_mul(throughput, Ld);
             L = v3_add(L, Ld);
             if (integrator == PT_INTEGRATOR_DL) break;
@@ -409,7 +422,7 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
             const v3 f = FN(matte_factor)(m, ray.d, new_dir);
             throughput = v3_mul(throughput, f);
             v3 Ld;
-            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, &Ld CTR_ARG);
+            FN(direct_light)(objects, n, lights, s0, s1, &hit, &nl, id, odd, &Ld CTR_ARG);
             Ld = v3_mul(throughput, Ld);
             L = v3_add(L, Ld);
             if (integrator == PT_INTEGRATOR_DL) break;

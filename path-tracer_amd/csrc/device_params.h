@@ -4,7 +4,7 @@
 // Device scene layout (built once per ptgpu_set_scene, all arrays of float4 in HBM, read-only):
 //
 //   prims  [3 * n_prims]   primitive p = the p-th non-MODEL object in index order
-//        sphere  : a = (center.xyz, radius)  b = (radius*radius, inside limit, 0, 0)   c = 0, or the vertex prefilter of a dropped sphere (enc_list below)
+//        sphere  : a = (center.xyz, radius)  b = (radius*radius, dropped, 0, 0)   c = 0   (dropped = 1: see enc_list below)
 //        triangle: a = (p1.xyz, 0)           b = (e1.xyz, 0) = p2 - p1      c = (e2.xyz, 0) = p3 - p1
 //     (e1, e2 and radius^2 are the same single float operations the reference performs on every
 //      test, geomfunc.h:17, 48-49, so hoisting them is bit-neutral.)
@@ -96,11 +96,12 @@ struct PtDeviceParams {
     // point at maxt instead of the ray - which lights, the light record says (l2.w); 0 = no such test
     unsigned ball_groups;
     // The ENCLOSED family of candidate sets (ptgpu.h) drops opaque spheres that hold a whole light for the rays that
-    // start WELL INSIDE them: enc_list[0 .. n_enc) (n_enc <= 32) = those spheres, as indices into the build's primary
-    // primitive array; the second quad of their records carries the limit in .y (|x - c|^2 below it = x is well inside;
-    // 0 in every other record), the third a conservative linear form of the same test (pt_enclosed_prefilter).  Every path vertex is checked against them; bit k of its mask = not well inside
-    // sphere enc_list[k], which its shadow rays then test.  self_sphere (PTGPU_CULL_ENCLOSED_SELF): a shadow ray is
-    // also tested against the dropped sphere its origin stands on.
+    // start INSIDE them: n_enc (<= 32) such spheres - in the fast build slots [0, n_enc) of the shadow order, in the
+    // strict build the records whose second quad says so in .y, named by enc_list[0 .. n_enc) (index order).
+    // The extension rays watch those spheres' answers: a path vertex found by a ray that did not get the far root of
+    // every one of them may lie outside one (upstream's paths do leave their room through its corners), and its
+    // shadow rays test them all.  self_sphere (PTGPU_CULL_ENCLOSED_SELF): a shadow ray is also tested against the
+    // dropped sphere its origin stands on.
     const int *enc_list;
     int n_enc;
     int self_sphere;

@@ -308,7 +308,7 @@ PtDeviceParams make_params(const ptgpu_ctx *c, const ImageTarget &img, int first
               : cull == PTGPU_CULL_BALL     ? c->d_smask_ball
                                             : nullptr;
     p.self_sphere = cull == PTGPU_CULL_ENCLOSED_SELF && p.smask ? 1 : 0;
-    // the spheres the ENCLOSED family dropped: every path vertex is checked against them (radiance_kernels.inc, vertex_needs)
+    // the spheres the ENCLOSED family dropped: the extension rays watch their answers (radiance_device.inc, sphere_t_odd)
     const bool family = cull == PTGPU_CULL_ENCLOSED || cull == PTGPU_CULL_BALL || cull == PTGPU_CULL_ENCLOSED_SELF;
     p.n_enc = family && p.smask ? c->n_enc : 0;
     p.enc_list = c->math == PTGPU_MATH_STRICT ? c->d_enc_index : c->d_enc_slot;
@@ -383,8 +383,8 @@ struct ShadowTables {
     std::vector<unsigned long long> safe, tight, enclosed, ball;
     std::vector<unsigned> light_ball;                // per light: sphere groups tested by the ray's end point (BALL)
     std::vector<float4> enclosing;                   // spheres ENCLOSED dropped from at least one set
-    std::vector<uint8_t> self_flag;                  // per primitive: such a sphere (its record carries the "well inside"
-                                                     // limit in the second quad's .y; 0 elsewhere)
+    std::vector<uint8_t> self_flag;                  // per primitive: such a sphere (its record says so in the second
+                                                     // quad's .y: 1, 0 elsewhere)
     std::vector<int> enc_index, enc_slot;            // those spheres (<= 32) in index order / as shadow-order slots
     bool tables_built = false;
     int levels = 0;                                  // of the range table appended to safe / tight / enclosed / ball
@@ -431,16 +431,13 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
     const bool enclosed_rule = mode == PTGPU_CULL_ENCLOSED || ball_rule || self_rule;
     if (enclosed_rule) mode = PTGPU_CULL_TIGHT;
     std::vector<uint8_t> encloses(n_prims, 0), ruled(n_lights, 0); // sphere i encloses some light; light l has sets
-    // the spheres the ENCLOSED rule may drop: opaque, with a usable "well inside" limit, the first 32 of them (the
-    // kernels keep, per path vertex, a bit per dropped sphere: is the vertex well inside it?)
+    // the spheres the ENCLOSED rule may drop: opaque, the first 32 of them (BALL keeps a bit per such sphere, and the
+    // kernels test every one of them for the rare vertex that may be outside one: a short list)
     std::vector<uint8_t> droppable(n_prims, 0);
     if (enclosed_rule) {
         int n = 0;
-        for (size_t i = 0; i < n_prims && n < 32; ++i) {
-            if (types[i] != PT_SPHERE || dielectric[i]) continue;
-            const float4 a = prims[3 * i];
-            if (pt_enclosed_inside_limit(a.w, a.x, a.y, a.z) > 0.f) { droppable[i] = 1; ++n; }
-        }
+        for (size_t i = 0; i < n_prims && n < 32; ++i)
+            if (types[i] == PT_SPHERE && !dielectric[i]) { droppable[i] = 1; ++n; }
     }
     const double eps = (double)PT_EPSILON;
     for (size_t l = 0; l < n_lights; ++l) {
@@ -508,9 +505,9 @@ std::vector<uint8_t> shadow_candidates(const std::vector<float4> &prims, const s
         for (size_t l = 0; l < n_lights; ++l)
             for (size_t i = 0; i < n_prims; ++i)
                 if (ruled[l] && encloses[i] && keep[l * n_prims + i]) keep[l * n_prims + i] = 2;
-    // A sphere the rule took out of some light's set is still tested, whatever the light, by the rays whose origin is
-    // not well inside it (4; ptgpu.h: upstream's paths do leave their room through its corners) - under ENCLOSED_SELF
-    // also by the rays that start ON it (3)
+    // A sphere the rule took out of some light's set is still tested, whatever the light, by the rays of a path vertex
+    // that may lie outside a dropped sphere (4; ptgpu.h: upstream's paths do leave their room through its corners) -
+    // under ENCLOSED_SELF also by the rays that start ON it (3)
     if (enclosed_rule)
         for (size_t l = 0; l < n_lights; ++l)
             for (size_t i = 0; i < n_prims; ++i)
@@ -815,19 +812,14 @@ void build_shadow_tables(const std::vector<float4> &prims, const std::vector<int
             if (dropped) t.enclosing.push_back(prims[3 * i]); // (centre, radius)
             t.self_flag[i] = dropped && types[i] == PT_SPHERE;
         }
-        // the dropped spheres, in each build's numbering, and their "well inside" limit in the record (second quad, .y)
+        // the dropped spheres, in each build's numbering, flagged in their records (second quad, .y)
         for (size_t i = 0; i < n_prims; ++i)
             if (t.self_flag[i]) t.enc_index.push_back((int)i);
         for (size_t slot = 0; slot < t.prim_of_slot.size(); ++slot) {
             const int i = t.prim_of_slot[slot];
             if (i < 0 || !t.self_flag[i]) continue;
             t.enc_slot.push_back((int)slot);
-            const float4 a = prims[3 * i];
-            const float lim = pt_enclosed_inside_limit(a.w, a.x, a.y, a.z);
-            float pre[4];
-            pt_enclosed_prefilter(a.w, a.x, a.y, a.z, lim, pre);
-            t.sprims[3 * slot + 1].y = t.sprims_planes[3 * slot + 1].y = lim;
-            t.sprims[3 * slot + 2] = t.sprims_planes[3 * slot + 2] = make_float4(pre[0], pre[1], pre[2], pre[3]);
+            t.sprims[3 * slot + 1].y = t.sprims_planes[3 * slot + 1].y = 1.f;
         }
     }
 
@@ -1240,14 +1232,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
     for (size_t k = 0; k < st.enc_slot.size(); ++k) // (the fast build's kernels walk slots [0, n_enc): build_shadow_tables sorts them first)
         if (st.enc_slot[k] != (int)k) return fail(PTGPU_ERR_STATE, "internal: the dropped spheres are not the first slots of the shadow order");
     for (size_t i = 0; i < st.self_flag.size(); ++i) // (index-order records: the strict build's primary array)
-        if (st.self_flag[i]) {
-            const float4 a = geo.prims[3 * i];
-            const float lim = pt_enclosed_inside_limit(a.w, a.x, a.y, a.z);
-            float pre[4];
-            pt_enclosed_prefilter(a.w, a.x, a.y, a.z, lim, pre);
-            geo.prims[3 * i + 1].y = lim;
-            geo.prims[3 * i + 2] = make_float4(pre[0], pre[1], pre[2], pre[3]);
-        }
+        if (st.self_flag[i]) geo.prims[3 * i + 1].y = 1.f;
     if (info.lights >= (1u << 18)) { // the near-queue tag holds 18 bits of light index
         st.cluster_bounds.clear();
         st.cluster_table.clear();
@@ -1347,6 +1332,7 @@ int ptgpu_set_scene(ptgpu_ctx *ctx, const pt_object *objects, uint32_t object_co
         ctx->enclosing = st.enclosing;
         HIP_TRY(upload(ctx->d_enc_index, st.enc_index));
         HIP_TRY(upload(ctx->d_enc_slot, st.enc_slot));
+
         ctx->n_enc = (int)st.enc_index.size();
         HIP_TRY(upload(ctx->d_cmask, st.cluster_masks));
         HIP_TRY(upload(ctx->d_cbounds, st.cluster_table));

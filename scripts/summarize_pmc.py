@@ -1,5 +1,8 @@
 """Sum rocprofv3 --pmc CSV rows of the dominant radiance kernel (one directory per pass) and derive the
-figures bench.py and DESIGN.md quote.  usage: summarize_pmc.py <pmc dir> <workload key> <render passes of the profiled run> [out.json]
+figures bench.py and DESIGN.md quote.  usage: summarize_pmc.py <pmc dir> <workload key> <render passes of the profiled run> [out.json [kernel_resources.json]]
+(kernel_resources.json: scripts/kernel_resources.py - the compiler's own register / spill / scratch figures per kernel.
+rocprofv3's VGPR_Count column counts in granules of 4 where gfx950's wave64 kernels are allotted granules of 8: it
+reads 40 for this library's 80-register kernels; it is kept as `vgpr_count_rocprof` and the compiler's figure is `vgprs`.)
 
 Derived (MI355X_MICROARCH.md, rocprofv3 PMC slots / HBM):
   active_lane_fraction    SQ_THREAD_CYCLES_VALU / (64 x SQ_INSTS_VALU)   (thread-cycles per issued wave instruction)
@@ -33,8 +36,16 @@ n_disp = max(len(v) for v in disp[kernel].values())
 g = lambda n: c.get(n)
 # `passes` = render passes of the whole profiled run (scripts/profile_r02.sh: 2), however many dispatches they took
 out = {"kernel": kernel, "dispatches_per_pmc_pass": n_disp, "passes": passes,
-       "vgpr": g("_vgpr"), "sgpr": g("_sgpr"), "lds_block_bytes": g("_lds"), "scratch_bytes_per_lane": g("_scratch"),
-       "workgroup_size": g("_wg")}
+       "vgpr_count_rocprof": g("_vgpr"), "sgpr_count_rocprof": g("_sgpr"), "lds_block_bytes": g("_lds"),
+       "scratch_bytes_per_lane": g("_scratch"), "workgroup_size": g("_wg")}
+if len(sys.argv) > 5 and os.path.exists(sys.argv[5]):   # the compiler's figures for this kernel (scripts/kernel_resources.py)
+    res = json.load(open(sys.argv[5]))
+    short = kernel.split("(")[0].strip()
+    short = short[5:] if short.startswith("void ") else short
+    for name, v in res.items():
+        if name == short:
+            out.update({k: v[k] for k in ("vgprs", "sgprs", "sgpr_spill", "vgpr_spill", "waves_per_simd") if k in v})
+            out["scratch_bytes_per_lane_compiler"] = v.get("scratch_bytes_per_lane")
 for name in sorted(c):
     if not name.startswith("_"):
         out[name] = c[name]

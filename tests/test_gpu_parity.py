@@ -315,7 +315,7 @@ def test_scene_info_reports_shadow_tables_and_clusters():
     g.set_scene(pt.LoadedScene("obj-model", 32, 24))                        # nothing to cull: no tables, no bins
     info = g.scene_info()
     assert info["clusters"] == 0 and info["shadow_tests_tight"] == info["primitives"] == 322
-    for opt, bad in ((pt.OPT_SHADOW_CULL, 6), (pt.OPT_SHADOW_CULL, -1), (pt.OPT_WORK_QUEUE, 3), (10, 0)):
+    for opt, bad in ((pt.OPT_SHADOW_CULL, 7), (pt.OPT_SHADOW_CULL, -1), (pt.OPT_WORK_QUEUE, 3), (10, 0)):
         with pytest.raises(pt.GpuError):
             g.set_option(opt, bad)
     g.close()
@@ -601,8 +601,10 @@ def test_headline_build_has_no_bias_beyond_its_candidate_sets(size):
         1024x768x4 (measured 2e-6 .. 7e-6; sampling noise of the mean there 1.2e-5) and <= 2.5e-4 at 256x192x64
         (measured 3e-5 .. 8e-5; noise 7e-5) - the one-sided 2.4e-4 that the plain v_sqrt_f32 gave the sphere
         test is what this pins (radiance_device.inc f_sqrt_refined);
-      ENCLOSED sets on top: one-signed, 0 .. +3e-4 per channel (measured +0.7e-4 .. +1.4e-4: the acne of
-        the wall spheres it takes out of the shadow scans, geomfunc.h:10-39; DESIGN.md 4.3);
+      ENCLOSED sets on top (the default): the same bound, |mean bias| <= 1e-4 per channel (2.5e-4 at 256x192x64).
+        Until round 3 this was one-signed, +0.7e-4 .. +1.4e-4: paths leave the room through its corners
+        (geomfunc.h:36, t > EPSILON) and ENCLOSED lit what they found outside; the extension ray's far-root check
+        hands those vertices back to the full scan (DESIGN.md 4.3; measured -2e-6 .. +1e-5 since);
       relative RMSE <= 5 % at these sample counts (flipped decisions swap whole samples: noise, measured
         1.8 % and 2.8 %); 8x8-block means: 99 % of the blocks within 1.5 %, mean deviation <= 0.3 %;
       NaN pixels (the reference's black fireflies) within 2 of each other."""
@@ -613,22 +615,22 @@ def test_headline_build_has_no_bias_beyond_its_candidate_sets(size):
     bias, rel_rmse, nan, blocks = _fast_against_strict(w, h, spp, pt.CULL_ENCLOSED)
     print(f"fast + ENCLOSED vs strict {w}x{h}x{spp}: bias {bias}, rel rmse {rel_rmse:.4f}, nan {nan}, "
           f"blocks p99 {np.quantile(blocks, .99):.4f} mean {blocks.mean():.5f}")
-    assert (bias >= -0.5e-4).all() and (bias <= 3e-4).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
+    assert (np.abs(bias) <= (1e-4 if w * h * spp > 3.1e6 else 2.5e-4)).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
     assert np.quantile(blocks, .99) <= 0.015 and blocks.mean() <= 3e-3
 
 
-def test_config5_scene_enclosed_rule_for_its_sphere_light_moves_the_image_by_the_walls_acne_only():
+def test_config5_scene_enclosed_rule_for_its_sphere_light_does_not_move_the_image():
     """cornell-large.txt (BASELINE config 5's scene; one sphere light inside six wall spheres) at 1024x768x8:
     fast math with the plain scan (TIGHT culls nothing here, so the library scans everything): |bias| <= 1e-4 per
-    channel (measured +3e-5, noise 2e-5); the default, ENCLOSED for the sphere light: one-signed, 0 .. +4e-4
-    (measured +1.3e-4 .. +2.4e-4: the acne of the six walls, as on cornell.txt); relative RMSE <= 5 %."""
+    channel (measured +3e-5, noise 2e-5); the default, ENCLOSED for the sphere light: the same bound (it was
+    one-signed +1.3e-4 .. +2.4e-4 before the far-root check, see the test above); relative RMSE <= 5 %."""
     w, h, spp = 1024, 768, 8
     bias, rel_rmse, nan, _ = _fast_against_strict(w, h, spp, pt.CULL_TIGHT, "cornell-large")
     print(f"cornell-large fast + plain scan vs strict: bias {bias}, rel rmse {rel_rmse:.4f}")
     assert (np.abs(bias) <= 1e-4).all() and rel_rmse <= 0.05 and nan[0] == nan[1]
     bias, rel_rmse, nan, _ = _fast_against_strict(w, h, spp, pt.CULL_ENCLOSED, "cornell-large")
     print(f"cornell-large fast + ENCLOSED vs strict: bias {bias}, rel rmse {rel_rmse:.4f}")
-    assert (bias >= 0).all() and (bias <= 4e-4).all() and rel_rmse <= 0.05 and nan[0] == nan[1]
+    assert (np.abs(bias) <= 1e-4).all() and rel_rmse <= 0.05 and abs(nan[0] - nan[1]) <= 2
 
 
 def test_c_host_cli_end_to_end(tmp_path):

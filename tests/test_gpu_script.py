@@ -112,7 +112,7 @@ def test_scripted_session_matches_the_oracle_driven_by_the_same_events(tmp_path,
     got, gw, gh = read_ppm(tmp_path / shots[0])
     assert snapshot[3] == 5 and (gw, gh) == (w, h) and (got == (snapshot[0].reshape(h, w) & 0xffffff)).all()
     # every frame line reports the camera the events left
-    assert r.stderr.count("frame ") == 8
+    assert r.stderr.count("frame ") == 7
 
 
 def test_script_errors_exit_like_the_reference(tmp_path):

@@ -8,11 +8,11 @@ What is proven here on the CPU
     light's plane, and moves the image by less than the calibrated FP floor (it can differ only for
     rays that graze the light's own plane, where the contribution's cosine factor is ~0);
   * ENCLOSED is TIGHT minus the opaque spheres a light lies wholly inside - for the rays that start
-    well inside those spheres (keep value 4: every path vertex is checked, upstream's paths do leave
-    their room through its corners) - never drops a dielectric sphere or a sphere the light pokes out
-    of, and moves the image by 1e-6 .. 1e-5 of its radiance, no sign (upstream's float "acne" on the
-    sphere a shadow ray starts from); round 2's version assumed the paths stay inside and was
-    brighter than upstream by 1.1e-4, one-signed;
+    inside those spheres (keep value 4: every path vertex is checked through the extension ray that
+    found it, upstream's paths do leave their room through its corners) - never drops a dielectric
+    sphere or a sphere the light pokes out of, and moves the image by 1e-6 .. 1e-5 of its radiance,
+    no sign (upstream's float "acne" on the sphere a shadow ray starts from); round 2's version
+    assumed the paths stay inside and was brighter than upstream by 1.1e-4, one-signed;
   * ENCLOSED_SELF (keep value 3: also the rays that start ON a dropped sphere test it) is TIGHT, bit
     for bit.
 """
@@ -127,7 +127,7 @@ def test_enclosed_drops_only_opaque_spheres_around_the_light():
     o, real, lights = geometry(sc)
     tight = pt.shadow_candidates(sc, pt.CULL_TIGHT)
     enc = pt.shadow_candidates(sc, pt.CULL_ENCLOSED)
-    # 4: a dropped sphere stays for the rays that start not well inside it - whatever the light, also where TIGHT
+    # 4: a dropped sphere stays for the rays of a vertex that may be outside one - whatever the light, also where TIGHT
     # itself culls the sphere (the kernels keep one bit per vertex and sphere, not per light; testing more than a
     # set asks for is upstream's own scan)
     assert set(np.unique(enc)) <= {0, 1, 4} and ((enc == 1) <= (tight == 1)).all()
@@ -182,7 +182,8 @@ def test_paths_leave_the_room_through_its_corners_and_enclosed_keeps_their_walls
     # sphere" (4 -> 0: round 2's ENCLOSED), the oracle's mismatch log shows shadow rays that the full scan finds
     # occluded by a wall the origin is OUTSIDE of (a bounce ray that starts within EPSILON of a second wall passes
     # through it, geomfunc.h:36) - every light of such a vertex, and that is the one-signed bias.  With the
-    # per-vertex check (4) the only mismatches left are rays occluded by the sphere they start on.
+    # per-vertex check (4: did the ray that found the vertex get every dropped sphere's far root?) the mismatches
+    # left are rays occluded by the sphere they start on - or, within rounding of a corner, by its neighbour.
     import ctypes as C
     lib = ob.oracle()
     lib.oracle_set_mismatch_log.argtypes = [C.c_void_p, C.c_int]
@@ -219,9 +220,12 @@ def test_paths_leave_the_room_through_its_corners_and_enclosed_keeps_their_walls
     outside = np.array(outside)
     print(f"assumed-inside sets: {len(lost)} shadow rays lose a sphere occluder; {own.sum()} start on it, "
           f"{(~own).sum()} elsewhere, of which {(outside > 0).sum()} start outside that sphere (median {np.median(outside):+.3f})")
-    assert (~own).sum() > 500 and (outside > -0.04).all() and (outside > 0).mean() > 0.9
+    assert (~own).sum() > 500 and (outside > -0.01).all() and (outside > 0).mean() > 0.9
     kept = mismatches(enc)
-    assert len(kept) > 0 and (kept[:, 8] == kept[:, 9]).all()    # what is left: rays occluded by the sphere they stand on
+    depth = np.array([float(o["radius"][int(r[9])]) - np.linalg.norm(r[:3].astype(np.float64) - o["center"][int(r[9])].astype(np.float64))
+                      for r in kept])
+    assert len(kept) > 0 and (np.abs(depth) < 0.01).all()        # what is left: acne, origins within rounding of the sphere
+    assert (kept[:, 8] == kept[:, 9]).mean() > 0.99
 
 
 def test_ball_marks_the_enclosing_spheres_a_light_reaches_out_of():

@@ -26,6 +26,8 @@ The JSON line also carries
                is NOT what `frac` is built from.
   image_error  the benchmarked (fast) build against the strict build - which equals the reference bit for bit
                (tests) - same seeds, same spp, full frame: RMSE, mean bias, NaN pixels.
+  exact_algorithm  secondary rates of the same workload (not `value`): fast math + SAFE sets, fast math +
+               ENCLOSED_SELF (= TIGHT's image bit for bit in the strict build) and the strict build's default.
   cpu_baseline the CPU oracle (a bit-exact port of the reference's main-cpu.c path) timed on this host's cores
                on a bounded sample of the same scene.
 """
@@ -68,12 +70,27 @@ def spawn_ranks(n):
     return subprocess.run(cmd).returncode
 
 
-def cpu_baseline(scene_name):
+def cpu_threads(asked):
+    """Threads of the CPU leg: every core this process may run on.  The GPU pool allots a share of the machine to
+    a one-GPU box and states it in OMP_NUM_THREADS (16; os.cpu_count() there shows the whole machine): that share
+    is taken when set, otherwise the affinity mask.  --cpu-threads overrides; os.cpu_count() is printed either way."""
+    if asked > 0:
+        return asked
+    env = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    if env > 0:
+        return env
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(scene_name, threads_asked=0):
     """Rank 0, N = 1 only.  oracle/ is used here as the timed CPU baseline and the reference's flop counter."""
     sys.path.insert(0, os.path.join(REPO, "oracle"))
     import oracle_binding as ob
     import pyptgpu as pt
-    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    threads = cpu_threads(threads_asked)
     # flops per path of the reference algorithm (full scans), counted on a 96x72 frame (serial, counting build)
     cw, ch = 96, 72
     sc = pt.LoadedScene(scene_name, cw, ch)
@@ -100,6 +117,10 @@ def cpu_baseline(scene_name):
     return {
         "value": bw * bh * spp / t_all / 1e6, "unit": "Mpaths/s", "cores": threads, "kind": "port",
         "sample": f"{scene_name} {bw}x{bh} x {spp} spp, {threads} OpenMP threads over rows, {t_all:.1f} s",
+        "host_cpu_count": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+        "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"),
+        "cores_note": "cores = OMP_NUM_THREADS when the pool sets it (its CPU share of the machine per GPU), else the affinity mask; "
+                      "--cpu-threads N overrides.  The oracle scales with rows: value x host_cpu_count / cores bounds the whole machine",
         "single_thread_value": one,
         "single_thread_sample": f"{scene_name} {cw}x{ch} x {passes_one} spp, serial loop as main-cpu.c, {t_one:.1f} s",
     }, ctr.flops() / ctr.paths, ctr.as_dict()
@@ -128,6 +149,26 @@ def executed_work(pt, args, make_gpu, w, h):
     return flops, per_path, f"{args.scene}.txt {cw}x{ch} x {passes} spp, counting build", li
 
 
+def exact_algorithm_rates(pt, make_gpu, sc, seeds, w, h, passes):
+    """Secondary figures, outside the timed region: the same workload through the builds that run the reference's
+    algorithm with no candidate-set rule of this library's own - fast math + SAFE sets (statistical parity by the
+    arithmetic alone) and the strict build with its default (bit-exact with the CPU path).  HIP-event times, best of 3."""
+    rates = {}
+    for name, math, cull in (("fast_safe", pt.MATH_FAST, pt.CULL_SAFE), ("fast_enclosed_self", pt.MATH_FAST, pt.CULL_ENCLOSED_SELF),
+                             ("strict_default", pt.MATH_STRICT, pt.CULL_AUTO)):
+        g = make_gpu(math=math, cull=cull)
+        g.set_scene(sc)
+        g.resize(w, h, seeds)
+        n = passes if math == pt.MATH_FAST else max(1, passes // 4)
+        g.render_timed(n)
+        ms = min(g.render_timed(n) for _ in range(3))
+        li = g.launch_info()
+        g.close()
+        rates[name] = {"Mpaths_per_s": w * h * n / ms / 1e3, "passes": n, "ms": ms, "shadow_cull": li["shadow_cull"],
+                       "kernel": "wavefront" if li["kernel"] == pt.KERNEL_WAVEFRONT else "mega"}
+    return rates
+
+
 def image_error(pt, make_gpu, sc, seeds, w, h, spp):
     """fast build (as benchmarked) against the strict build (= the reference, bit for bit) at equal seeds/spp."""
     import numpy as np
@@ -154,11 +195,16 @@ def image_error(pt, make_gpu, sc, seeds, w, h, spp):
 
 
 def committed_profile(workload_key):
-    """Per-pass PMC figures of a committed rocprofv3 run of this workload (profiles/r02/pmc_summary.json)."""
-    try:
-        return json.load(open(os.path.join(REPO, "profiles", "r02", "pmc_summary.json"))).get(workload_key)
-    except (OSError, ValueError):
-        return None
+    """Per-pass PMC figures of the newest committed rocprofv3 run of this workload (profiles/rNN/pmc_summary.json)."""
+    for rnd in ("r03", "r02"):
+        try:
+            prof = json.load(open(os.path.join(REPO, "profiles", rnd, "pmc_summary.json"))).get(workload_key)
+        except (OSError, ValueError):
+            prof = None
+        if prof:
+            prof["round"] = rnd
+            return prof
+    return None
 
 
 def keep_stdout_for_the_line():
@@ -193,6 +239,8 @@ def main():
     ap.add_argument("--passes-per-launch", type=int, default=0, help="0 = automatic")
     ap.add_argument("--backend", default="nccl", help="process-group backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = OMP_NUM_THREADS, else every core of the affinity mask)")
+    ap.add_argument("--no-exact", action="store_true", help="skip the secondary timings of the exact-algorithm builds")
     ap.add_argument("--no-count", action="store_true", help="skip the counting-build run (roofline is then null)")
     ap.add_argument("--no-image-error", action="store_true", help="skip the fast-vs-strict comparison")
     ap.add_argument("--key-only", action="store_true", help="render one pass and print the workload key (scripts/profile_r02.sh)")
@@ -311,7 +359,7 @@ def main():
 
         baseline = ref_flops_per_path = ref_counters = None
         if world == 1 and not args.no_cpu:
-            baseline, ref_flops_per_path, ref_counters = cpu_baseline(args.scene)
+            baseline, ref_flops_per_path, ref_counters = cpu_baseline(args.scene, args.cpu_threads)
         roofline = None
         if not args.no_count:   # (per launch on one GPU: rank 0's kernel stands for every rank's at N > 1)
             flops_per_path, per_path, count_sample, count_li = executed_work(pt, args, make_gpu, w, h)
@@ -327,7 +375,7 @@ def main():
                 issued = {"tflops": tf, "frac": tf / PEAK_FP32_VALU_TFLOPS, "flops_per_path": fl / (w * h),
                           "active_lane_fraction": prof["active_lane_fraction"],
                           "occupancy_waves_per_cu": prof.get("occupancy_waves_per_cu"),
-                          "source": "profiles/r02/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes) x this run's step time" % workload_key}
+                          "source": "profiles/%s/pmc_summary.json[%s] (rocprofv3 --pmc, separate passes) x this run's step time" % (prof["round"], workload_key)}
                 if prof.get("FETCH_SIZE_bytes_per_pass") is not None and prof.get("WRITE_SIZE_bytes_per_pass") is not None:
                     traffic = (prof["FETCH_SIZE_bytes_per_pass"] + prof["WRITE_SIZE_bytes_per_pass"]) * args.passes
             roofline = {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
@@ -354,6 +402,9 @@ def main():
         err = None
         if world == 1 and args.math == "fast" and not args.no_image_error:
             err = image_error(pt, make_gpu, sc, seeds, w, h, min(16, args.passes))
+        exact = None
+        if world == 1 and args.math == "fast" and not args.no_exact:
+            exact = exact_algorithm_rates(pt, make_gpu, sc, seeds, w, h, args.passes)
         line = {
             "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "ranks_seen": ranks_seen,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -365,6 +416,7 @@ def main():
                        "parallelism": f"passes split over {world} GPU(s) by seed block + 1 all-reduce of the float4 sample buffer "
                                       f"per {args.steps * args.passes} passes per rank"},
             "workload_key": workload_key, "roofline": roofline, "cpu_baseline": baseline, "image_error": err,
+            "exact_algorithm": exact,
             "speedup_vs_cpu_all_cores": (value / world / baseline["value"]) if baseline else None,
             "speedup_vs_cpu_single_thread": (value / world / baseline["single_thread_value"]) if baseline else None,
             "reference_counters_sample": ref_counters,

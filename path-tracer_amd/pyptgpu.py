@@ -317,8 +317,11 @@ WORK_SLOTS = ("sphere_tests", "triangle_tests_mt", "triangle_tests_planes", "bvh
               "shadow_rays", "rng_draws", "paths", "node_lane_slots", "prim_lane_slots", "convex_plane_tests")
 
 
+ERR_ARGUMENT, ERR_STATE, ERR_DEVICE, ERR_MEMORY = -1, -2, -3, -4   # ptgpu.h ptgpu_status
+
+
 class GpuError(RuntimeError):
-    pass
+    code = None   # the ptgpu_status a C-ABI call returned, where one did
 
 
 VARIANT_DIR = os.path.join(HERE, "variants")
@@ -330,10 +333,34 @@ def variant_path(name):
     return os.path.join(VARIANT_DIR, "libptgpu_%s.so" % name)
 
 
+def hip_runtimes_mapped():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps)."""
+    seen = []
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                if path not in seen:
+                    seen.append(path)
+    return seen
+
+
+def check_single_hip_runtime():
+    """libptgpu.so needs libamdhip64.so.7 and takes whichever copy of that SONAME is already mapped; torch loads its
+    bundled copy by path.  Loaded in the order torch -> libptgpu there is one runtime; in the order libptgpu -> torch
+    there are two, and the one that comes second does not find the GPU (or worse, both run it).  Refuse that state."""
+    mapped = hip_runtimes_mapped()
+    if len(mapped) > 1:
+        raise GpuError("two HIP runtimes are mapped into this process (%s): import torch (or whatever else brings its own "
+                       "libamdhip64) BEFORE the first pyptgpu.gpu() / ptgpu_create, so that libptgpu.so binds to that copy"
+                       % ", ".join(mapped))
+
+
 def gpu(path=None):
     """libptgpu.so (or, with `path`, a variant build of it), loaded once per path.  Raises if the HIP
-    extension has not been built."""
+    extension has not been built, or if loading it leaves two HIP runtimes in the process."""
     global _gpu
+    check_single_hip_runtime()
     if path is not None:
         if path not in _variants:
             if not os.path.exists(path):
@@ -346,6 +373,7 @@ def gpu(path=None):
             raise GpuError("libptgpu.so is missing: build it with `make -C path-tracer_amd/csrc` "
                            "(there is no CPU fallback for the radiance path)")
         _gpu = _bind(C.CDLL(path))
+        check_single_hip_runtime()
     return _gpu
 
 
@@ -405,8 +433,18 @@ def hip_runtime():
         lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         lib.hipGetErrorString.restype = C.c_char_p
         lib.hipGetErrorString.argtypes = [C.c_int]
+        lib.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         _hip = lib
     return _hip
+
+
+def device_memory_free():
+    """hipMemGetInfo's free bytes on the current device (tests: an entry point that must not allocate)."""
+    free, total = C.c_size_t(), C.c_size_t()
+    e = hip_runtime().hipMemGetInfo(C.byref(free), C.byref(total))
+    if e != 0:
+        raise GpuError("hipMemGetInfo: HIP error %d" % e)
+    return free.value
 
 
 class DeviceBuffer:
@@ -502,7 +540,9 @@ class Gpu:
 
     def _ok(self, rc):
         if rc != 0:
-            raise GpuError("ptgpu status %d: %s" % (rc, self.lib.ptgpu_last_error().decode()))
+            e = GpuError("ptgpu status %d: %s" % (rc, self.lib.ptgpu_last_error().decode()))
+            e.code = rc
+            raise e
 
     def set_option(self, opt, value):
         self._ok(self.lib.ptgpu_set_option(self.ctx, opt, value))

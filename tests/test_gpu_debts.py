@@ -80,6 +80,15 @@ def test_launch_info_names_what_ran():
     g.finish()
     li = g.launch_info()
     assert (li["kernel"], li["instance"], li["work_queue"], li["shadow_cull"]) == (pt.KERNEL_MEGA, 0, 0, pt.CULL_OFF)
+    # the queue rule looks at the scene's cost per pass, not at how many passes this call asked for:
+    # materials.txt's passes are cheap - no queue, for render(1) and for render(64) alike; cornell.txt: a queue for both
+    for scene, queue in (("materials", 0), ("cornell", 1)):
+        g.set_scene(pt.LoadedScene(scene, w, h))
+        g.resize(w, h, pt.seed_block(w, h))
+        for n in (1, 64):
+            g.render(n)
+            g.finish()
+            assert g.launch_info()["work_queue"] == queue, (scene, n)
     g.close()
 
 

@@ -92,3 +92,45 @@ def test_render_static_refuses_what_it_cannot_hold_and_needs_no_resize():
     finally:
         g.close()
         buf.free()
+
+
+def test_render_static_allocates_no_device_memory_and_one_context_at_a_time_owns_the_queue():
+    """(1) hipMemGetInfo's free bytes are the same before and after a run of calls (after one warm-up call: the first
+    call on a device resolves the array's address and may load code).  (2) The static array is one per GPU: while a
+    context's call may still be in flight (no ptgpu_finish yet) another context's call on that GPU is refused with
+    PTGPU_ERR_STATE instead of racing; after the owner's ptgpu_finish the other context renders, and its image equals
+    ptgpu_render's."""
+    w, h = 96, 64
+    sc = pt.LoadedScene("cornell", w, h)
+    seeds = pt.seed_block(w, h)
+    a, b = pt.Gpu(0, pt.INTEGRATOR_PT), pt.Gpu(0, pt.INTEGRATOR_PT)
+    bufs = [pt.DeviceBuffer(w * h * pt.COLOR_STRIDE_FLOATS * 4), pt.DeviceBuffer(w * h * 4), pt.DeviceBuffer(2 * w * h * 4)]
+    try:
+        a.set_scene(sc)
+        b.set_scene(sc)
+        bufs[2].upload(seeds)
+        a.render_static(w, h, 0, 1, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)   # warm-up
+        a.finish()
+        free_before = pt.device_memory_free()
+        for i, (ww, hh) in enumerate(((96, 64), (40, 24), (96, 64))):
+            a.render_static(ww, hh, 1 + i, 2, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        a.finish()
+        assert pt.device_memory_free() == free_before
+        # ownership
+        a.render_static(w, h, 0, 4, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        with pytest.raises(pt.GpuError, match="in use by another context") as e:
+            b.render_static(w, h, 0, 1, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)
+        assert e.value.code == pt.ERR_STATE
+        a.finish()
+        bufs[2].upload(seeds)
+        got = static_render(b, w, h, seeds, 0, 2)
+        want = reference_render(sc, w, h, seeds, pt.MATH_FAST, 0, 2)
+        assert got[0].tobytes() == want[0].tobytes() and (got[1] == want[1]).all() and (got[2] == want[2]).all()
+        b.finish()
+        a.render_static(w, h, 0, 1, bufs[0].ptr, bufs[1].ptr, bufs[2].ptr)   # and back
+        a.finish()
+    finally:
+        a.close()
+        b.close()
+        for x in bufs:
+            x.free()

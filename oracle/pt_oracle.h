@@ -87,6 +87,9 @@ void oracle_set_enclosing(const uint8_t *flags);
  * object the ray starts on, the first object the full scan reports, its distance, the culled answer. */
 void oracle_set_mismatch_log(float *records, int capacity);
 int  oracle_mismatch_count(void);
+/* every ray of a serial render, 12 floats a record (radiance_oracle.c) */
+void oracle_set_ray_log(float *records, long capacity);
+long oracle_ray_count(void);
 
 int oracle_max_threads(void);
 

@@ -98,6 +98,29 @@ void oracle_set_mismatch_log(float *records, int capacity) {
 }
 int oracle_mismatch_count(void) { return g_mismatch_count; }
 
+/* Diagnostic (serial renders, plain instance): every ray the render traces, 12 floats a record - kind (0 extension,
+ * 1 shadow), origin, direction, maxt (1e20 for an extension ray), answer (extension: distance, 0 for a miss; shadow:
+ * 1 + the first occluder in index order, 0 if free), extension: object hit or -1 / shadow: the occluder's distance,
+ * the slot y * width + x of the pixel, the segment of the path.  Used by
+ * scripts/flipped_rays.py to put the same rays to the GPU builds through the ray probe. */
+static float *g_ray_log = NULL;
+static long g_ray_capacity = 0, g_ray_count = 0;
+static int g_ray_pixel = 0, g_ray_depth = 0;
+void oracle_set_ray_log(float *records, long capacity) {
+    g_ray_log = records;
+    g_ray_capacity = capacity;
+    g_ray_count = 0;
+}
+long oracle_ray_count(void) { return g_ray_count; }
+static void log_ray(int kind, const pt_ray *ray, float maxt, float answer, float id) {
+    if (!g_ray_log || g_ray_count >= g_ray_capacity) return;
+    float *r = g_ray_log + 12 * g_ray_count++;
+    r[0] = (float)kind;
+    r[1] = ray->o.x; r[2] = ray->o.y; r[3] = ray->o.z;
+    r[4] = ray->d.x; r[5] = ray->d.y; r[6] = ray->d.z;
+    r[7] = maxt; r[8] = answer; r[9] = id; r[10] = (float)g_ray_pixel; r[11] = (float)g_ray_depth;
+}
+
 /* ---- instance 1: plain ---- */
 #define FN(name) plain_##name
 #define TALLY(field) ((void)0)

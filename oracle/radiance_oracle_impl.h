@@ -222,6 +222,18 @@ static void FN(direct_light)(const pt_object *objects, uint32_t n, uint32_t ligh
             }
         }
 #endif
+#ifndef ORACLE_COUNTING
+        if (g_ray_log && (wi > 0.f)) { /* answer = 1 + the first occluder of the reference's scan (0: none), id = its distance */
+            float first = 0.f, first_t = 0.f;
+            for (uint32_t k = 0; k < n && first == 0.f; k++) {
+                float dist = 0.f;
+                if (objects[k].type == PT_SPHERE) dist = FN(hit_sphere)(&objects[k], &shadow CTR_ARG);
+                else if (objects[k].type == PT_TRIANGLE) dist = FN(hit_triangle)(&objects[k], &shadow CTR_ARG);
+                if ((dist != 0.f) && (dist < len - PT_EPSILON)) { first = (float)(k + 1); first_t = dist; }
+            }
+            log_ray(1, &shadow, len - PT_EPSILON, first, first_t);
+        }
+#endif
         if ((wi > 0.f) && (!FN(any_hit)(objects, n, &shadow, len - PT_EPSILON, candidates, origin_id, origin_odd CTR_ARG))) {
             const float s = light->area * wi * wo / (len * len);
             const v3 contribution = v3_scale(s, light->emission);
@@ -357,6 +369,15 @@ static void FN(radiance)(const pt_object *objects, uint32_t n, uint32_t lights, 
         float t;
         uint32_t id = 0;
         int odd = 0;
+#ifndef ORACLE_COUNTING
+        if (g_ray_log) {
+            g_ray_depth = (int)depth;
+            float lt;
+            uint32_t lid = 0;
+            const int found = FN(closest_hit)(objects, n, &ray, &lt, &lid, NULL CTR_ARG);
+            log_ray(0, &ray, 1e20f, found ? lt : 0.f, found ? (float)lid : -1.f);
+        }
+#endif
         if (!FN(closest_hit)(objects, n, &ray, &t, &id, &odd CTR_ARG)) {
             /* miss: throughput * sky, DISCARDING what was gathered so far (quirk A.3-2) */
             const v3 sky_dir = v3_make(-.41f, -.82f, .41f);
@@ -448,6 +469,9 @@ static void FN(render_rows)(const pt_object *objects, uint32_t n, uint32_t light
             uint32_t *s0 = &seeds[2 * sslot], *s1 = &seeds[2 * sslot + 1];
             pt_ray ray;
             FN(camera_ray)(cam, x, y, width, height, s0, s1, &ray CTR_ARG);
+#ifndef ORACLE_COUNTING
+            g_ray_pixel = y * width + x;
+#endif
             v3 sample;
             FN(radiance)(objects, n, lights, &ray, s0, s1, scene->sky1, scene->sky2, materials,
                          integrator, &sample CTR_ARG);

@@ -1,7 +1,7 @@
 """BVH A/B: strict bit-exactness of BVH on vs off (and vs the oracle), then 1024x768 timing."""
 import sys, os
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import oracle_binding as ob, pyptgpu as pt
 for name, w, h, spp in (("obj-model", 64, 48, 3), ("large-object", 40, 30, 1), ("complex", 64, 48, 2), ("cornell", 48, 36, 2),

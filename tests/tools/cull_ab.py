@@ -1,7 +1,7 @@
 """Shadow-cull A/B: strict bit-exactness of SAFE/TIGHT against OFF and the oracle, then cornell 1024x768 timing."""
 import sys, os
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import oracle_binding as ob, pyptgpu as pt
 for name, w, h, spp in (("cornell", 40, 24, 2), ("materials", 64, 48, 3), ("cornell", 96, 72, 4)):

@@ -5,7 +5,7 @@ the modes and of the library builds named on the command line.
 usage: enclosed_family.py [--skip-replay] [lib.so ...]"""
 import sys, os, time
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import pyptgpu as pt
 args = sys.argv[1:]

@@ -1,7 +1,7 @@
 """First GPU contact: mega kernel, strict and fast, against the CPU oracle on small images."""
 import sys, time, os
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import oracle_binding as ob, pyptgpu as pt
 

@@ -1,7 +1,7 @@
 """Quick A/B: parity spot check (strict bit-exact) + cornell 1024x768 timing of the kernel variants."""
 import sys, os
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "oracle")); sys.path.insert(0, os.path.join(REPO, "path-tracer_amd"))
 import oracle_binding as ob, pyptgpu as pt
 for name, w, h, spp in (("cornell", 40, 24, 2), ("materials", 64, 48, 3), ("obj-model", 32, 24, 2)):

@@ -4,7 +4,7 @@ of every light's candidate set (mathematically they cannot occlude a segment bet
 them; numerically the float discriminant can report the sphere a ray starts on)."""
 import os, sys
 import numpy as np
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(REPO, "path-tracer_amd")); sys.path.insert(0, os.path.join(REPO, "oracle"))
 import pyptgpu as pt, oracle_binding as ob
 name = sys.argv[1] if len(sys.argv) > 1 else "cornell"

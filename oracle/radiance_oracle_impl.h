@@ -470,7 +470,7 @@ static void FN(render_rows)(const pt_object *objects, uint32_t n, uint32_t light
             pt_ray ray;
             FN(camera_ray)(cam, x, y, width, height, s0, s1, &ray CTR_ARG);
 #ifndef ORACLE_COUNTING
-            g_ray_pixel = y * width + x;
+            if (g_ray_log) g_ray_pixel = y * width + x; /* (serial renders only; unconditionally, every thread would write this line) */
 #endif
             v3 sample;
             FN(radiance)(objects, n, lights, &ray, s0, s1, scene->sky1, scene->sky2, materials,

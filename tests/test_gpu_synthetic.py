@@ -244,3 +244,44 @@ def test_closed_convex_clusters_are_tested_by_their_face_planes():
     cpu = ob.Render(sc, pt.seed_block(w, h), ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(1, threads=8)
     got = render(sc, w, h, 1, math=pt.MATH_STRICT, kernel=pt.KERNEL_WAVEFRONT, ray_bins=1)
     assert (got[2] == cpu.seeds).all() and same_bits(got[0], cpu.colors)
+
+
+def nested_room(shells):
+    """`shells` opaque spheres around the whole scene (concentric, radii 2000, 2001, ...), a triangle light, two
+    diffuse balls: every shell holds the light, so the ENCLOSED family may drop up to 32 of them."""
+    objs = [sphere(2000.0 + k, (0, 40, 80), color=(.6, .6, .6)) for k in range(shells)]
+    light = np.array([[[-10, 70, 70], [10, 70, 70], [0, 70, 90]], [[-10, 70, 70], [0, 70, 90], [-12, 70, 88]]], dtype=np.float32)
+    objs += [triangles(light, emission=(30, 30, 30)),                          # normals (0, -1, 0): facing down
+             sphere(12, (-15, 12, 70), color=(.8, .3, .3)), sphere(9, (18, 9, 95), color=(.3, .8, .3)),
+             triangles(np.array([[[-60, 0, 20], [60, 0, 20], [60, 0, 140]], [[-60, 0, 20], [60, 0, 140], [-60, 0, 140]]], dtype=np.float32))]
+    return objs
+
+
+@pytest.mark.parametrize("shells", [6, 32, 40], ids=["6 shells", "32 shells", "40 shells"])
+def test_enclosed_family_with_up_to_and_beyond_32_dropped_spheres_equals_its_replay(shells):
+    # The kernels watch the dropped spheres as the first n_enc <= 32 slots of the shadow order; a scene with more
+    # enclosing spheres than that keeps the others in the sets.  Strict build + each mode = the oracle replaying
+    # the same byte matrix, both kernels; and the matrix drops exactly min(shells, 32) spheres for both lights.
+    w, h, spp = 64, 48, 2
+    sc = make_scene(nested_room(shells), w, h)
+    seeds = pt.seed_block(w, h)
+    for cull in (pt.CULL_ENCLOSED, pt.CULL_ENCLOSED_SELF, pt.CULL_BALL):
+        keep = pt.shadow_candidates(sc, cull)
+        dropped = ((keep == 4) | (keep == 3)).sum(1)
+        assert (dropped == min(shells, 32)).all(), (cull, dropped)
+        with ob.shadow_candidates(keep):
+            cpu = ob.Render(sc, seeds, ob.SEEDS_KERNEL_LAYOUT, 0).pass_oracle(spp, threads=8)
+        for kernel in (pt.KERNEL_MEGA, pt.KERNEL_WAVEFRONT):
+            g = pt.Gpu(0, 0, math=pt.MATH_STRICT, kernel=kernel, shadow_cull=cull, bvh=pt.BVH_OFF)
+            g.set_scene(sc)
+            g.resize(w, h, seeds)
+            g.render(spp)
+            g.finish()
+            assert g.launch_info()["shadow_cull"] == cull
+            assert same_bits(g.colors(), cpu.colors) and (g.seeds() == cpu.seeds).all(), (shells, cull, kernel)
+            g.close()
+    # and the fast build's default against the strict build with the reference's own scan: no drift
+    a = render(sc, 128, 96, 16, math=pt.MATH_FAST)[0]
+    b = render(sc, 128, 96, 16, math=pt.MATH_STRICT, shadow_cull=pt.CULL_OFF, bvh=pt.BVH_OFF)[0]
+    ok = np.isfinite(a).all(1) & np.isfinite(b).all(1)
+    assert abs((a[ok].astype(np.float64) - b[ok]).mean()) <= 2e-3 * b[ok].mean()

@@ -201,8 +201,10 @@ int ptgpu_render_timed(ptgpu_ctx *ctx, int first_sample, int n_passes, float *el
  * to WAVEFRONT and 1.  Asynchronous on the context's stream; ptgpu_finish as usual.
  * Limit: PTGPU_STATIC_MAX_TILES tiles (a 4096x4096 frame; 1 MiB of device memory per GPU, held until
  * the process ends); a larger frame is refused with PTGPU_ERR_ARGUMENT.  Every call on one GPU shares
- * that GPU's array: calls that overlap on a GPU (two contexts, or two streams' worth of work from
- * different threads) race - serialise them, e.g. ptgpu_finish between contexts. */
+ * that GPU's array and its contents of the last call (the library clears what must start at zero).  One
+ * context at a time owns a GPU's array - from its call until its ptgpu_finish or ptgpu_destroy; another
+ * context's call on that GPU in between returns PTGPU_ERR_STATE instead of racing.  Calls of ONE context are
+ * ordered by its stream; two threads driving one context are the caller's to serialise, as for every call here. */
 #define PTGPU_STATIC_MAX_TILES 262142
 int ptgpu_render_static(ptgpu_ctx *ctx, int width, int height, int first_sample, int n_passes,
                         void *colors_dev, uint32_t *pixels_dev, uint32_t *seeds_dev);
